@@ -1,0 +1,128 @@
+/* libsdamd -- C ABI of the MI355X-native (gfx950) kernels behind the SD-v1.5 denoising hot path.
+ *
+ * The reference (KhoaDuong2005/Stable-Diffusion) has no FFI: its "operators" are torch.nn
+ * calls inside Python modules.  Each entry point below names the reference lines it replaces;
+ * the Python host code in stable-diffusion_amd/ binds them with ctypes.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless stated; nothing here allocates, frees or
+ *     synchronises; `stream` is a hipStream_t (0 = default stream), so every call can be
+ *     captured into a hipGraph;
+ *   - `dtype`: SDAMD_F32 (0) or SDAMD_BF16 (1) = storage type of activations/weights;
+ *     accumulation is always f32, biases / norm gains are always f32;
+ *   - activations are NHWC ([B][H][W][C], i.e. [tokens][C]); caller tensors at module
+ *     boundaries are NCHW f32 and are converted by the boundary kernels;
+ *   - return 0 on success; non-zero = argument/launch error, text in sdamd_last_error()
+ *     (thread-local).  Nothing throws across the boundary.
+ */
+#ifndef SDAMD_H
+#define SDAMD_H
+#include <stddef.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SDAMD_F32 0
+#define SDAMD_BF16 1
+#define SDAMD_ACT_NONE 0
+#define SDAMD_ACT_QUICK_GELU 1 /* x*sigmoid(1.702x), clip.py:67 */
+#define SDAMD_ACT_SILU 2       /* diffusion.py:163 */
+
+const char* sdamd_last_error(void);
+int sdamd_abi_version(void);
+int sdamd_device_count(void); /* >=0, or -hipError when no driver/GPU */
+
+/* ---- sampler: pipeline.py:147-153 (CFG combine) + sampler/ddpm.py:55-87 (step), one launch.
+ * latents [B][n] f32 in/out; eps [2B][n] f32 = UNet output, [pos_0..pos_B-1, neg_0..neg_B-1]
+ * (do_cfg=0: eps [B][n]); noise [steps][B][n] pre-drawn host noise (may be null when no row
+ * has has_noise); coef [steps][8] = {sqrt(abar_t), sqrt(1-abar_t), c0, cx, sigma, has_noise,0,0}
+ * computed on the host with the reference's own torch ops; the schedule index is *step_ptr
+ * (device int, for graph replay) or `step` when step_ptr is null. Bit-exact vs torch CPU. */
+int sdamd_cfg_ddpm_step(float* latents, const float* eps, const float* noise, const float* coef,
+                        const int* step_ptr, int step, float cfg_scale, int do_cfg, int B, int n,
+                        void* stream);
+int sdamd_counter_add(int* counter, int delta, void* stream);
+/* sampler/ddpm.py:91-111: out = sqrt_abar*x + sqrt_one_minus_abar*noise */
+int sdamd_add_noise(float* out, const float* x, const float* noise, float sqrt_abar,
+                    float sqrt_one_minus_abar, long long total, void* stream);
+/* dst[0:width] = table[idx][0:width], idx = *step_ptr or step (per-step time-bias rows) */
+int sdamd_gather_row(float* dst, const float* table, const int* step_ptr, int step, int width,
+                     void* stream);
+
+/* ---- normalisation: nn.GroupNorm(32,C)(+F.silu) diffusion.py:26-28,38-40,93,292-294,
+ * decoder.py:25-30,49,118-120; x,y NHWC [B][HW][C]; ws >= sdamd_groupnorm_ws_bytes(B). */
+size_t sdamd_groupnorm_ws_bytes(int B);
+int sdamd_groupnorm_nhwc(const void* x, void* y, const float* gamma, const float* beta, void* ws,
+                         int B, int HW, int C, float eps, int silu, int dtype, void* stream);
+/* nn.LayerNorm(C): diffusion.py:109,117,126; clip.py:54,63,95 */
+int sdamd_layernorm(const void* x, void* y, const float* gamma, const float* beta, int rows, int C,
+                    float eps, int dtype, void* stream);
+/* softmax(scores*scale) per row, f32 in, dtype out (unfused d_head=512 VAE attention) */
+int sdamd_softmax_rows(const float* scores, void* probs, int rows, int n, float scale, int dtype,
+                       void* stream);
+
+/* ---- elementwise */
+/* diffusion.py:128-130: in [rows][2F] (value|gate) -> out [rows][F] = value*gelu_erf(gate) */
+int sdamd_geglu(const void* in, void* out, long long rows, int F, int dtype, void* stream);
+/* clip.py:13-19: out[r] = table[ids[r]] + pos[r % S]; ids int64 device */
+int sdamd_clip_embed(const long long* ids, const void* table, const void* pos, void* out, int rows,
+                     int S, int D, int vocab, int dtype, void* stream);
+/* diffusion.py:277 torch.cat(dim=1) in NHWC */
+int sdamd_concat_nhwc(const void* a, const void* b, void* out, long long pixels, int C1, int C2,
+                      int dtype, void* stream);
+int sdamd_add(const void* a, const void* b, void* out, long long numel, int dtype, void* stream);
+int sdamd_nchw_to_nhwc(const float* src, void* dst, int B, int C, int HW, int dtype, void* stream);
+int sdamd_nhwc_to_nchw(const void* src, float* dst, int B, int C, int HW, int dtype, void* stream);
+int sdamd_cast(const void* src, void* dst, long long n, int src_dtype, int dst_dtype, void* stream);
+/* F.silu on an f32 vector (diffusion.py:32) */
+int sdamd_silu(const float* src, float* dst, long long n, void* stream);
+int sdamd_transpose(const void* src, void* dst, int batch, int rows, int cols, int ld_src,
+                    long long stride_src, long long stride_dst, int dtype, void* stream);
+/* pipeline.py:158-160: rescale (-1,1)->(0,255), clamp, truncating cast; NCHW f32 -> NHWC u8 */
+int sdamd_image_to_uint8(const float* src, unsigned char* dst, int B, int HW, void* stream);
+/* pipeline.py:99-104: uint8 HWC -> NCHW f32 in (-1,1) */
+int sdamd_uint8_to_image(const unsigned char* src, float* dst, int B, int HW, void* stream);
+/* decoder.py:76,128: y = conv1x1_{4->4}(x/0.18215), NCHW f32; w [4][4], b [4] f32 */
+int sdamd_vae_post_quant(const float* x, float* y, const float* w, const float* b, int B, int HW,
+                         void* stream);
+/* encoder.py:57,70-84: conv1x1_{8->8} + clamp/exp/sqrt/sample/scale; x NCHW f32 [B][8][HW] */
+int sdamd_vae_sample(const float* x, const float* noise, float* out, const float* w, const float* b,
+                     int B, int HW, void* stream);
+
+/* ---- MFMA GEMM: nn.Linear / conv1x1 (attention.py:19-20,81-85; diffusion.py:18,54,82-85,
+ * 156-157; clip.py:45-46).  C[m][n] = act(sum_k A[m][k]*W[n][k] + bias[n] + residual[m][n]);
+ * K % 64 == 0, N % 16 == 0; `batch` independent problems with element strides. */
+int sdamd_gemm(const void* A, const void* W, void* C, const float* bias, const void* residual, int M,
+               int N, int K, int lda, int ldw, int ldc, int ldr, int batch, long long strideA,
+               long long strideW, long long strideC, long long strideR, int act, int dtype,
+               int out_f32, void* stream);
+/* ---- implicit-GEMM conv3x3 over NHWC: nn.Conv2d(k=3) of diffusion.py:9,13,146,204-221,
+ * decoder.py:10-13,92-111, encoder.py:13-45.  w [Cout][ky][kx][Cin]; pad_mode 0 = pad 1,
+ * 1 = bottom/right pad only (encoder.py:65-66); upsample=1 fuses F.interpolate(nearest,2x)
+ * (diffusion.py:148-150, decoder.py:90); residual [B][Ho][Wo][Cout] or null. */
+int sdamd_conv3x3(const void* x, const void* w, void* y, const float* bias, const void* residual,
+                  int B, int H, int W, int Cin, int Cout, int stride, int pad_mode, int upsample,
+                  int act, int dtype, int out_f32, void* stream);
+/* first convs (diffusion.py:196, decoder.py:78, encoder.py:10): x NCHW f32, Cin 3|4,
+ * w [ky][kx][Cin][Cout] f32 -> y NHWC dtype */
+int sdamd_conv3x3_cin_small(const float* x_nchw, const float* w_tap_ci_co, const float* bias,
+                            void* y_nhwc, int B, int H, int W, int Cin, int Cout, int dtype,
+                            void* stream);
+/* last convs (diffusion.py:287, decoder.py:123, encoder.py:54): x NHWC dtype, Cout 3|4|8,
+ * w [tap][Cin/V][Cout][V] dtype (V = 16 bytes of dtype) -> y NCHW f32 */
+int sdamd_conv3x3_cout_small(const void* x_nhwc, const void* w_packed, const float* bias,
+                             float* y_nchw, int B, int H, int W, int Cin, int Cout, int dtype,
+                             void* stream);
+
+/* ---- MFMA flash attention: attention.py:47-68 (self, optional causal) and :112-127 (cross);
+ * replaces customtriton.py / flash_attention.py outright.  q/k/v/out are [B][S][row stride]
+ * with head h at columns [h*d,(h+1)*d); strides in elements; d in {40,64,80,160}. */
+int sdamd_attention(const void* q, const void* k, const void* v, void* out, int B, int H, int Sq,
+                    int Skv, int d, long long q_bs, int q_rs, long long k_bs, int k_rs,
+                    long long v_bs, int v_rs, long long o_bs, int o_rs, int causal, int dtype,
+                    void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

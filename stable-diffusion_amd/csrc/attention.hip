@@ -1,0 +1,252 @@
+// MFMA flash attention for gfx950 -- replaces the eager softmax(QK^T)V of attention.py:47-68,
+// 112-127 and the Triton path (customtriton.py, flash_attention.py) of the reference.
+// No S x S matrix is materialised: one workgroup = 4 waves = 128 query rows of one (batch, head);
+// each wave owns 32 query rows and sweeps the keys in LDS-staged tiles of 32 with an online
+// softmax.  Scores are computed transposed, S^T = K Q^T (32x32 MFMA, key on the accumulator row,
+// query on the lane), so a query's running max / sum are lane-local (one cross-half exchange)
+// and the exponentiated tile is already the B operand of the O^T += V^T P^T MFMAs.
+//   bf16: v_mfma_f32_32x32x16_bf16; V^T fragments come from row-major V in LDS through
+//         ds_read_b64_tr_b16 (hardware transpose read).
+//   f32 : v_mfma_f32_32x32x2_f32 (exact f32); one element per lane per MFMA, so V is read
+//         row-major with ds_read_b32 and no transpose is needed.
+// Head dims of SD-v1.5: 40 / 80 / 160 (UNet), 64 (CLIP).  The contraction dim of QK^T is padded
+// with zeros to DK, the output dim of PV to DV (multiples of the MFMA tile).  KV lengths that are
+// not a multiple of 32 (77-token cross attention / CLIP) are masked; `causal` masks key > query
+// (mask before scale, attention.py:55-61 -- identical for -inf).
+#include "common.h"
+
+struct AttnArgs {
+  const void* Q; const void* K; const void* V; void* O;
+  int H, Sq, Skv;
+  long long q_bs, k_bs, v_bs, o_bs;  // batch strides, elements
+  int q_rs, k_rs, v_rs, o_rs;        // token strides, elements; head h starts at column h*D
+  float scale_log2e;                 // log2(e) / sqrt(D)
+  int causal;
+};
+
+__device__ __forceinline__ s16x4_t lds_read_tr16(const char* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(p));
+}
+
+template <typename T, int D> struct AttnCfg;
+template <int D> struct AttnCfg<bf16_t, D> {
+  static constexpr int DK = (D + 15) / 16 * 16;
+  static constexpr int DV = (D + 31) / 32 * 32;
+  static constexpr int KS = DK * 2 + 16;                             // K row stride (bytes): odd multiple of 16
+  static constexpr int VS = (DV * 2) % 256 == 64 || (DV * 2) % 256 == 192 ? DV * 2 : DV * 2 + 64;  // 4 rows x 64 B tile a bank row
+};
+template <int D> struct AttnCfg<float, D> {
+  static constexpr int DK = D;  // multiple of 8
+  static constexpr int DV = (D + 31) / 32 * 32;
+  static constexpr int KS = DK * 4 + 16;
+  static constexpr int VS = DV * 4;
+};
+
+template <typename T, int D>
+__global__ __launch_bounds__(256) void attn_kernel(const AttnArgs p) {
+  typedef AttnCfg<T, D> Cfg;
+  constexpr int DK = Cfg::DK, DV = Cfg::DV, KS = Cfg::KS, VS = Cfg::VS;
+  constexpr int EPC = 16 / sizeof(T);
+  constexpr int KC = DK / EPC, VC = DV / EPC, DC = D / EPC;  // 16-byte chunks per row
+  constexpr int NB = DV / 32;                                // 32-wide output blocks
+  constexpr bool BF = sizeof(T) == 2;
+  constexpr int NQ = BF ? DK / 16 : D / 8;                   // Q fragments (4 VGPR each)
+  __shared__ __attribute__((aligned(16))) char smem[32 * KS + 32 * VS];
+  char* ks = smem;
+  char* vs = smem + 32 * KS;
+
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int b = blockIdx.y / p.H, head = blockIdx.y % p.H;
+  const int q0 = blockIdx.x * 128 + wave * 32;
+  const int qrow = q0 + r;
+  const T* __restrict__ Qp = (const T*)p.Q + (size_t)b * p.q_bs + (size_t)head * D;
+  const T* __restrict__ Kp = (const T*)p.K + (size_t)b * p.k_bs + (size_t)head * D;
+  const T* __restrict__ Vp = (const T*)p.V + (size_t)b * p.v_bs + (size_t)head * D;
+
+  // Q fragments (B operand): lane (r, h) holds Q[qrow][...] for its k slots
+  u32x4_t qf[NQ];
+  {
+    const T* qr = Qp + (size_t)min(qrow, p.Sq - 1) * p.q_rs;
+#pragma unroll
+    for (int s = 0; s < NQ; ++s) {
+      const int d0 = BF ? 16 * s + 8 * h : 8 * s + 4 * h;
+      u32x4_t z = {0u, 0u, 0u, 0u};
+      if (d0 < D) z = *reinterpret_cast<const u32x4_t*>(qr + d0);
+      qf[s] = z;
+    }
+  }
+
+  f32x16_t o[NB];
+#pragma unroll
+  for (int i = 0; i < NB; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) o[i][e] = 0.f;
+  float m_run = -1.0e30f, l_run = 0.f;
+
+  // causal: this block needs keys 0 .. q0_block+127 only
+  int kv_end = p.Skv;
+  if (p.causal) kv_end = min(p.Skv, (int)blockIdx.x * 128 + 128);
+  const int ntiles = (kv_end + 31) / 32;
+
+  for (int kt = 0; kt < ntiles; ++kt) {
+    const int kv0 = kt * 32;
+    __syncthreads();  // previous tile fully consumed
+    // stage K (32 x DK) and V (32 x DV), zero-filling pad columns and rows >= Skv
+    for (int c = t; c < 32 * KC; c += 256) {
+      int row = c / KC, ch = c - row * KC;
+      u32x4_t z = {0u, 0u, 0u, 0u};
+      if (ch < DC && kv0 + row < p.Skv) z = *reinterpret_cast<const u32x4_t*>(Kp + (size_t)(kv0 + row) * p.k_rs + ch * EPC);
+      *reinterpret_cast<u32x4_t*>(ks + row * KS + ch * 16) = z;
+    }
+    for (int c = t; c < 32 * VC; c += 256) {
+      int row = c / VC, ch = c - row * VC;
+      u32x4_t z = {0u, 0u, 0u, 0u};
+      if (ch < DC && kv0 + row < p.Skv) z = *reinterpret_cast<const u32x4_t*>(Vp + (size_t)(kv0 + row) * p.v_rs + ch * EPC);
+      *reinterpret_cast<u32x4_t*>(vs + row * VS + ch * 16) = z;
+    }
+    __syncthreads();
+
+    // S^T = K Q^T : rows = keys (accumulator registers), cols = queries (lanes)
+    f32x16_t s;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) s[e] = 0.f;
+    if constexpr (BF) {
+#pragma unroll
+      for (int st = 0; st < NQ; ++st) {
+        bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(ks + r * KS + (16 * st + 8 * h) * 2);
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, __builtin_bit_cast(bf16x8_t, qf[st]), s, 0, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int g = 0; g < NQ; ++g) {
+        f32x4_t kf = *reinterpret_cast<const f32x4_t*>(ks + r * KS + (8 * g + 4 * h) * 4);
+        f32x4_t qv = __builtin_bit_cast(f32x4_t, qf[g]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[e], qv[e], s, 0, 0, 0);
+      }
+    }
+
+    // mask + online softmax (base-2 domain)
+    float mx = -1.0e30f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int key = kv0 + (e & 3) + 8 * (e >> 2) + 4 * h;
+      float v = s[e] * p.scale_log2e;
+      if (key >= p.Skv || (p.causal && key > qrow)) v = -1.0e30f;
+      s[e] = v;
+      mx = fmaxf(mx, v);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = exp2f(m_run - m_new);
+    float rs = 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      float pe = exp2f(s[e] - m_new);
+      s[e] = pe;
+      rs += pe;
+    }
+    rs += __shfl_xor(rs, 32, 64);
+    l_run = l_run * alpha + rs;
+    m_run = m_new;
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) o[i][e] *= alpha;
+
+    // O^T += V^T P^T
+    if constexpr (BF) {
+      bf16x8_t pf[2];
+#pragma unroll
+      for (int st = 0; st < 2; ++st) {
+        u32x4_t w;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) w[j] = pack_bf2(s[8 * st + 2 * j], s[8 * st + 2 * j + 1]);
+        pf[st] = __builtin_bit_cast(bf16x8_t, w);
+      }
+      // transpose read: lane 4q+p of each 16-lane group addresses row q, columns 4p..4p+3 of a
+      // 4-key x 16-column block; element j of the A fragment is key 16*st + 8*(j>>2) + 4h + (j&3)
+      const int g16 = lane >> 4, li = lane & 15;
+      const char* vbase = vs + (4 * (g16 >> 1) + (li >> 2)) * VS + (16 * (g16 & 1) + 4 * (li & 3)) * 2;
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+          s16x4_t lo = lds_read_tr16(vbase + (16 * st) * VS + i * 64);
+          s16x4_t hi = lds_read_tr16(vbase + (16 * st + 8) * VS + i * 64);
+          typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+          s16x8_t vv = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          o[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, vv), pf[st], o[i], 0, 0, 0);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int key = (e & 3) + 8 * (e >> 2) + 4 * h;
+          float a = *reinterpret_cast<const float*>(vs + key * VS + (i * 32 + r) * 4);
+          o[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, s[e], o[i], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  // epilogue: O[q][d] = O^T[d][q] / l ; lane holds d = 32i + 8*(e>>2) + 4h + (e&3)
+  if (qrow < p.Sq) {
+    const float inv = 1.0f / l_run;
+    T* op = (T*)p.O + (size_t)b * p.o_bs + (size_t)qrow * p.o_rs + (size_t)head * D;
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d0 = 32 * i + 8 * g + 4 * h;
+        if (d0 < D) {
+          float v0 = o[i][4 * g] * inv, v1 = o[i][4 * g + 1] * inv, v2 = o[i][4 * g + 2] * inv, v3 = o[i][4 * g + 3] * inv;
+          if constexpr (BF) {
+            u32x2_t w = {pack_bf2(v0, v1), pack_bf2(v2, v3)};
+            *reinterpret_cast<u32x2_t*>(op + d0) = w;
+          } else {
+            *reinterpret_cast<f32x4_t*>(op + d0) = (f32x4_t){v0, v1, v2, v3};
+          }
+        }
+      }
+    }
+  }
+}
+
+template <typename T, int D>
+static int launch_attn(const AttnArgs& a, int B, hipStream_t st) {
+  dim3 grid((a.Sq + 127) / 128, B * a.H);
+  attn_kernel<T, D><<<grid, 256, 0, st>>>(a);
+  SD_LAUNCH_CHECK("attention");
+  return 0;
+}
+
+// q/k/v/out: [B][S][row stride] with head h at columns [h*d, (h+1)*d); strides in elements.
+extern "C" int sdamd_attention(const void* q, const void* k, const void* v, void* out, int B, int H, int Sq, int Skv, int d,
+                               long long q_bs, int q_rs, long long k_bs, int k_rs, long long v_bs, int v_rs,
+                               long long o_bs, int o_rs, int causal, int dtype, void* stream) {
+  SD_CHECK(B > 0 && H > 0 && Sq > 0 && Skv > 0, "attention: empty problem B=%d H=%d Sq=%d Skv=%d", B, H, Sq, Skv);
+  SD_CHECK(d == 40 || d == 64 || d == 80 || d == 160, "attention: head dim %d not built (40, 64, 80, 160)", d);
+  SD_CHECK(dtype == SDAMD_BF16 || dtype == SDAMD_F32, "attention: bad dtype");
+  const int esz = dtype == SDAMD_BF16 ? 2 : 4;
+  SD_CHECK(((uintptr_t)q % 16) == 0 && ((uintptr_t)k % 16) == 0 && ((uintptr_t)v % 16) == 0 && ((uintptr_t)out % 16) == 0,
+           "attention: pointers must be 16-byte aligned");
+  SD_CHECK((q_rs * esz) % 16 == 0 && (k_rs * esz) % 16 == 0 && (v_rs * esz) % 16 == 0 && (o_rs * esz) % 16 == 0 &&
+               (q_bs * esz) % 16 == 0 && (k_bs * esz) % 16 == 0 && (v_bs * esz) % 16 == 0 && (o_bs * esz) % 16 == 0,
+           "attention: strides must keep 16-byte alignment");
+  SD_CHECK(!causal || Sq == Skv, "attention: causal needs Sq == Skv");
+  AttnArgs a;
+  a.Q = q; a.K = k; a.V = v; a.O = out; a.H = H; a.Sq = Sq; a.Skv = Skv;
+  a.q_bs = q_bs; a.k_bs = k_bs; a.v_bs = v_bs; a.o_bs = o_bs;
+  a.q_rs = q_rs; a.k_rs = k_rs; a.v_rs = v_rs; a.o_rs = o_rs;
+  a.scale_log2e = 1.4426950408889634f / sqrtf((float)d);
+  a.causal = causal;
+  hipStream_t st = (hipStream_t)stream;
+#define ATT(TT) switch (d) { case 40: return launch_attn<TT, 40>(a, B, st); case 64: return launch_attn<TT, 64>(a, B, st); \
+                             case 80: return launch_attn<TT, 80>(a, B, st); default: return launch_attn<TT, 160>(a, B, st); }
+  if (dtype == SDAMD_BF16) ATT(bf16_t) else ATT(float)
+#undef ATT
+}

@@ -1,0 +1,90 @@
+// Shared device helpers for the gfx950 (MI355X / CDNA4) kernels of libsdamd.
+// Wave = 64 lanes; bf16 is carried as raw 16-bit words, all arithmetic in f32.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define SDAMD_F32 0
+#define SDAMD_BF16 1
+
+typedef unsigned short bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;   // MFMA bf16 operand (4 VGPR)
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+
+__device__ __forceinline__ float bf2f(bf16_t u) { return __builtin_bit_cast(float, (unsigned)u << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {
+  __bf16 b = (__bf16)f;  // v_cvt_pk_bf16_f32: round-to-nearest-even, NaN stays NaN
+  return __builtin_bit_cast(bf16_t, b);
+}
+__device__ __forceinline__ unsigned pack_bf2(float lo, float hi) {
+  return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
+}
+
+template <typename T> struct Cvt;
+template <> struct Cvt<float> {
+  static __device__ __forceinline__ float ld(const float* p) { return *p; }
+  static __device__ __forceinline__ void st(float* p, float v) { *p = v; }
+};
+template <> struct Cvt<bf16_t> {
+  static __device__ __forceinline__ float ld(const bf16_t* p) { return bf2f(*p); }
+  static __device__ __forceinline__ void st(bf16_t* p, float v) { *p = f2bf(v); }
+};
+
+// 16-byte vector of T: 4 floats or 8 bf16
+template <typename T> struct Vec16 { static constexpr int N = 16 / sizeof(T); };
+
+template <typename T> __device__ __forceinline__ void load_vec(const T* p, float (&v)[16 / sizeof(T)]);
+template <> __device__ __forceinline__ void load_vec<float>(const float* p, float (&v)[4]) {
+  f32x4_t t = *reinterpret_cast<const f32x4_t*>(p);
+  v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
+}
+template <> __device__ __forceinline__ void load_vec<bf16_t>(const bf16_t* p, float (&v)[8]) {
+  u32x4_t t = *reinterpret_cast<const u32x4_t*>(p);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    v[2 * i] = __builtin_bit_cast(float, t[i] << 16);
+    v[2 * i + 1] = __builtin_bit_cast(float, t[i] & 0xffff0000u);
+  }
+}
+template <typename T> __device__ __forceinline__ void store_vec(T* p, const float (&v)[16 / sizeof(T)]);
+template <> __device__ __forceinline__ void store_vec<float>(float* p, const float (&v)[4]) {
+  f32x4_t t = {v[0], v[1], v[2], v[3]};
+  *reinterpret_cast<f32x4_t*>(p) = t;
+}
+template <> __device__ __forceinline__ void store_vec<bf16_t>(bf16_t* p, const float (&v)[8]) {
+  u32x4_t t;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) t[i] = pack_bf2(v[2 * i], v[2 * i + 1]);
+  *reinterpret_cast<u32x4_t*>(p) = t;
+}
+
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + expf(-x)); }
+__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float quick_gelu_f(float x) { return x / (1.0f + expf(-1.702f * x)); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// host-side error plumbing (defined in api.hip)
+extern "C" const char* sdamd_last_error();
+int sdamd_set_error(int code, const char* fmt, ...);
+#define SD_CHECK(cond, ...) do { if (!(cond)) return sdamd_set_error(1, __VA_ARGS__); } while (0)
+#define SD_LAUNCH_CHECK(name) do { hipError_t e_ = hipGetLastError(); \
+  if (e_ != hipSuccess) return sdamd_set_error(2, "%s: launch failed: %s", name, hipGetErrorString(e_)); } while (0)

@@ -1,0 +1,410 @@
+// HBM-bound elementwise kernels of the SD hot path: fused CFG-combine + DDPM step, GeGLU gate,
+// CLIP embedding, NHWC concat, layout conversions, image quantisation, VAE sampling.
+// Compiled with -ffp-contract=off: the sampler kernels must reproduce torch's separate
+// mul/sub/div/add roundings bit for bit (pipeline.py:149, sampler/ddpm.py:70-85,110).
+#include "common.h"
+
+// ---------------------------------------------------------------------------------------------
+// CFG combine + DDPM ancestral step, one launch (pipeline.py:147-153 + ddpm.py:55-87).
+//   eps    [2B][n]  UNet output, images laid out [pos_0..pos_B-1, neg_0..neg_B-1]
+//   lat    [B][n]   in/out
+//   noise  [steps][B][n] pre-drawn on the host with the reference's generator call order
+//   coef   [steps][8] = {sqrt(abar_t), sqrt(1-abar_t), c0, cx, sigma, has_noise, 0, 0}
+//   step_ptr: device int holding the schedule index (advanced by sdamd_counter_add between
+//   graph replays), or null to use `step`.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cfg_ddpm_step_kernel(float* __restrict__ lat, const float* __restrict__ eps,
+                                                            const float* __restrict__ noise, const float* __restrict__ coef,
+                                                            const int* __restrict__ step_ptr, int step, float cfg_scale,
+                                                            int do_cfg, int B, int n) {
+  const int s = step_ptr ? *step_ptr : step;
+  const float* c = coef + (size_t)s * 8;
+  const float sa = c[0], sb = c[1], c0 = c[2], cx = c[3], sigma = c[4];
+  const bool has_noise = c[5] != 0.0f;
+  const size_t total = (size_t)B * n;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    float e;
+    if (do_cfg) {
+      float ep = eps[i], en = eps[total + i];
+      e = cfg_scale * (ep - en) + en;
+    } else {
+      e = eps[i];
+    }
+    float x = lat[i];
+    float x0 = (x - sb * e) / sa;
+    float prev = x0 * c0 + cx * x;
+    if (has_noise) prev = prev + sigma * noise[(size_t)s * total + i];
+    lat[i] = prev;
+  }
+}
+
+__global__ void counter_add_kernel(int* c, int delta) { if (threadIdx.x == 0 && blockIdx.x == 0) *c += delta; }
+
+// x' = sqrt(abar) * x + sqrt(1-abar) * noise  (ddpm.py:91-111)
+__global__ __launch_bounds__(256) void add_noise_kernel(float* __restrict__ out, const float* __restrict__ x,
+                                                        const float* __restrict__ noise, float sa, float sb, size_t total) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256)
+    out[i] = sa * x[i] + sb * noise[i];
+}
+
+// dst[r][:] = table[idx][:] for idx = *step_ptr (or step): picks this step's row of a per-step
+// table (time-projection biases) so graph replays read fixed addresses.
+__global__ __launch_bounds__(256) void gather_row_kernel(float* __restrict__ dst, const float* __restrict__ table,
+                                                         const int* __restrict__ step_ptr, int step, int width) {
+  const int s = step_ptr ? *step_ptr : step;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < width; i += gridDim.x * 256) dst[i] = table[(size_t)s * width + i];
+}
+
+// ---------------------------------------------------------------------------------------------
+// GeGLU: in [rows][2F] (value | gate), out [rows][F] = value * gelu_erf(gate)  (diffusion.py:128-130)
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void geglu_kernel(const T* __restrict__ in, T* __restrict__ out, size_t rows, int F) {
+  constexpr int V = 16 / sizeof(T);
+  const int vpr = F / V;
+  const size_t total = rows * vpr;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    size_t r = i / vpr;
+    int cv = (int)(i - r * vpr);
+    const T* src = in + r * 2 * F + (size_t)cv * V;
+    float a[V], g[V];
+    load_vec<T>(src, a);
+    load_vec<T>(src + F, g);
+#pragma unroll
+    for (int j = 0; j < V; ++j) a[j] = a[j] * gelu_erf_f(g[j]);
+    store_vec<T>(out + r * F + (size_t)cv * V, a);
+  }
+}
+
+// CLIP embedding: out[b][s][:] = tok_table[ids[b][s]][:] + pos[s][:]  (clip.py:13-19)
+template <typename T>
+__global__ __launch_bounds__(256) void clip_embed_kernel(const long long* __restrict__ ids, const T* __restrict__ table,
+                                                         const T* __restrict__ pos, T* __restrict__ out, int rows,
+                                                         int S, int D, int vocab) {
+  constexpr int V = 16 / sizeof(T);
+  const int vpr = D / V;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < rows * vpr; i += gridDim.x * 256) {
+    int r = i / vpr, cv = i % vpr;
+    long long id = ids[r];
+    if (id < 0) id = 0;
+    if (id >= vocab) id = vocab - 1;
+    float a[V], p[V];
+    load_vec<T>(table + (size_t)id * D + (size_t)cv * V, a);
+    load_vec<T>(pos + (size_t)(r % S) * D + (size_t)cv * V, p);
+#pragma unroll
+    for (int j = 0; j < V; ++j) a[j] += p[j];
+    store_vec<T>(out + (size_t)r * D + (size_t)cv * V, a);
+  }
+}
+
+// NHWC channel concat: out[p][0:C1] = a[p], out[p][C1:C1+C2] = b[p]  (diffusion.py:277)
+template <typename T>
+__global__ __launch_bounds__(256) void concat_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ out,
+                                                     size_t pixels, int C1, int C2) {
+  constexpr int V = 16 / sizeof(T);
+  const int v1 = C1 / V, v2 = C2 / V, vt = v1 + v2;
+  const size_t total = pixels * vt;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    size_t p = i / vt;
+    int cv = (int)(i - p * vt);
+    const T* src = cv < v1 ? a + p * C1 + (size_t)cv * V : b + p * C2 + (size_t)(cv - v1) * V;
+    *reinterpret_cast<u32x4_t*>(out + p * (C1 + C2) + (size_t)cv * V) = *reinterpret_cast<const u32x4_t*>(src);
+  }
+}
+
+// out = a + b (same shape), used where a residual cannot ride a GEMM epilogue
+template <typename T>
+__global__ __launch_bounds__(256) void add_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ out,
+                                                  size_t nvec) {
+  constexpr int V = 16 / sizeof(T);
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (size_t)gridDim.x * 256) {
+    float x[V], y[V];
+    load_vec<T>(a + i * V, x);
+    load_vec<T>(b + i * V, y);
+#pragma unroll
+    for (int j = 0; j < V; ++j) x[j] += y[j];
+    store_vec<T>(out + i * V, x);
+  }
+}
+
+// layout / dtype conversions at module boundaries: NCHW f32 (caller's tensors) <-> NHWC T
+template <typename T>
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ src, T* __restrict__ dst, int C, int HW) {
+  __shared__ float tile[32][33];
+  const int n = blockIdx.z, c0 = blockIdx.y * 32, p0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  for (int i = ty; i < 32; i += 8) {
+    int c = c0 + i, p = p0 + tx;
+    tile[i][tx] = (c < C && p < HW) ? src[((size_t)n * C + c) * HW + p] : 0.f;
+  }
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8) {
+    int p = p0 + i, c = c0 + tx;
+    if (c < C && p < HW) Cvt<T>::st(dst + ((size_t)n * HW + p) * C + c, tile[tx][i]);
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const T* __restrict__ src, float* __restrict__ dst, int C, int HW) {
+  __shared__ float tile[32][33];
+  const int n = blockIdx.z, c0 = blockIdx.y * 32, p0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int i = ty; i < 32; i += 8) {
+    int p = p0 + i, c = c0 + tx;
+    tile[i][tx] = (c < C && p < HW) ? Cvt<T>::ld(src + ((size_t)n * HW + p) * C + c) : 0.f;
+  }
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8) {
+    int c = c0 + i, p = p0 + tx;
+    if (c < C && p < HW) dst[((size_t)n * C + c) * HW + p] = tile[tx][i];
+  }
+}
+// flat dtype cast (f32 <-> T), e.g. [B,S,D] token tensors at module boundaries
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void cast_kernel(const TI* __restrict__ src, TO* __restrict__ dst, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+    Cvt<TO>::st(dst + i, Cvt<TI>::ld(src + i));
+}
+
+// y = silu(x), f32 (time-embedding path: diffusion.py:32)
+__global__ __launch_bounds__(256) void silu_kernel(const float* __restrict__ src, float* __restrict__ dst, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] = silu_f(src[i]);
+}
+
+// decoded image NCHW f32 in (-1,1) -> uint8 NHWC: rescale to (0,255), clamp, TRUNCATE (pipeline.py:158-160)
+__global__ __launch_bounds__(256) void image_to_uint8_kernel(const float* __restrict__ src, unsigned char* __restrict__ dst,
+                                                             int B, int HW) {
+  const size_t total = (size_t)B * HW * 3;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    size_t n = i / ((size_t)HW * 3);
+    size_t r = i - n * (size_t)HW * 3;
+    int p = (int)(r / 3), c = (int)(r % 3);
+    float x = src[((size_t)n * 3 + c) * HW + p];
+    x -= -1.0f;
+    x *= 127.5f;
+    x += 0.0f;
+    x = fminf(fmaxf(x, 0.0f), 255.0f);
+    dst[i] = (unsigned char)x;  // truncation toward zero, like torch's float->uint8 cast
+  }
+}
+// uint8 HWC image -> NCHW f32 in (-1,1)  (pipeline.py:99-104)
+__global__ __launch_bounds__(256) void uint8_to_image_kernel(const unsigned char* __restrict__ src, float* __restrict__ dst,
+                                                             int B, int HW) {
+  const size_t total = (size_t)B * HW * 3;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    size_t n = i / ((size_t)HW * 3);
+    size_t r = i - n * (size_t)HW * 3;
+    int p = (int)(r / 3), c = (int)(r % 3);
+    float x = (float)src[i];
+    x -= 0.0f;
+    x *= (float)(2.0 / 255.0);
+    x += -1.0f;
+    dst[((size_t)n * 3 + c) * HW + p] = x;
+  }
+}
+
+// VAE decoder prologue: y = conv1x1_{4->4}(x / 0.18215) on NCHW f32 latents (decoder.py:76,128)
+__global__ __launch_bounds__(256) void vae_post_quant_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                             const float* __restrict__ w, const float* __restrict__ b,
+                                                             int B, int HW) {
+  const size_t total = (size_t)B * HW;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    size_t n = i / HW, p = i - n * HW;
+    float v[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) v[c] = x[(n * 4 + c) * HW + p] / 0.18215f;
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+      float acc = b[o];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc += w[o * 4 + c] * v[c];
+      y[(n * 4 + o) * HW + p] = acc;
+    }
+  }
+}
+
+// VAE encoder epilogue: m = conv1x1_{8->8}(x); latent = (mean + sqrt(exp(clamp(logvar,-30,20))) * noise) * 0.18215
+// (encoder.py:57,70-84); x NCHW f32 [B,8,HW], noise/out NCHW f32 [B,4,HW]
+__global__ __launch_bounds__(256) void vae_sample_kernel(const float* __restrict__ x, const float* __restrict__ noise,
+                                                         float* __restrict__ out, const float* __restrict__ w,
+                                                         const float* __restrict__ b, int B, int HW) {
+  const size_t total = (size_t)B * HW;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    size_t n = i / HW, p = i - n * HW;
+    float v[8], m[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) v[c] = x[(n * 8 + c) * HW + p];
+#pragma unroll
+    for (int o = 0; o < 8; ++o) {
+      float acc = b[o];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) acc += w[o * 8 + c] * v[c];
+      m[o] = acc;
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      float lv = fminf(fmaxf(m[4 + c], -30.0f), 20.0f);
+      float sd = sqrtf(expf(lv));
+      float z = m[c] + sd * noise[(n * 4 + c) * HW + p];
+      out[(n * 4 + c) * HW + p] = z * 0.18215f;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host entry points
+// ---------------------------------------------------------------------------------------------
+static inline int grid_for(size_t work_items) {
+  size_t g = (work_items + 255) / 256;
+  if (g > 4096) g = 4096;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+extern "C" int sdamd_cfg_ddpm_step(float* latents, const float* eps, const float* noise, const float* coef,
+                                   const int* step_ptr, int step, float cfg_scale, int do_cfg, int B, int n,
+                                   void* stream) {
+  SD_CHECK(B > 0 && n > 0, "cfg_ddpm_step: empty input B=%d n=%d", B, n);
+  SD_CHECK(latents && eps && coef, "cfg_ddpm_step: null pointer");
+  cfg_ddpm_step_kernel<<<grid_for((size_t)B * n), 256, 0, (hipStream_t)stream>>>(latents, eps, noise, coef, step_ptr, step,
+                                                                               cfg_scale, do_cfg, B, n);
+  SD_LAUNCH_CHECK("cfg_ddpm_step");
+  return 0;
+}
+
+extern "C" int sdamd_counter_add(int* counter, int delta, void* stream) {
+  counter_add_kernel<<<1, 64, 0, (hipStream_t)stream>>>(counter, delta);
+  SD_LAUNCH_CHECK("counter_add");
+  return 0;
+}
+
+extern "C" int sdamd_add_noise(float* out, const float* x, const float* noise, float sqrt_abar, float sqrt_one_minus_abar,
+                               long long total, void* stream) {
+  SD_CHECK(total > 0, "add_noise: empty input");
+  add_noise_kernel<<<grid_for((size_t)total), 256, 0, (hipStream_t)stream>>>(out, x, noise, sqrt_abar, sqrt_one_minus_abar,
+                                                                          (size_t)total);
+  SD_LAUNCH_CHECK("add_noise");
+  return 0;
+}
+
+extern "C" int sdamd_gather_row(float* dst, const float* table, const int* step_ptr, int step, int width, void* stream) {
+  SD_CHECK(width > 0, "gather_row: empty row");
+  gather_row_kernel<<<grid_for((size_t)width), 256, 0, (hipStream_t)stream>>>(dst, table, step_ptr, step, width);
+  SD_LAUNCH_CHECK("gather_row");
+  return 0;
+}
+
+#define DISPATCH_T(dtype, CALL_BF16, CALL_F32) do { if ((dtype) == SDAMD_BF16) { CALL_BF16; } else { CALL_F32; } } while (0)
+
+extern "C" int sdamd_geglu(const void* in, void* out, long long rows, int F, int dtype, void* stream) {
+  const int V = dtype == SDAMD_BF16 ? 8 : 4;
+  SD_CHECK(rows > 0 && F > 0 && F % V == 0, "geglu: bad shape rows=%lld F=%d", rows, F);
+  hipStream_t st = (hipStream_t)stream;
+  int g = grid_for((size_t)rows * (F / V));
+  DISPATCH_T(dtype, (geglu_kernel<bf16_t><<<g, 256, 0, st>>>((const bf16_t*)in, (bf16_t*)out, (size_t)rows, F)),
+             (geglu_kernel<float><<<g, 256, 0, st>>>((const float*)in, (float*)out, (size_t)rows, F)));
+  SD_LAUNCH_CHECK("geglu");
+  return 0;
+}
+
+extern "C" int sdamd_clip_embed(const long long* ids, const void* table, const void* pos, void* out, int rows, int S, int D,
+                                int vocab, int dtype, void* stream) {
+  const int V = dtype == SDAMD_BF16 ? 8 : 4;
+  SD_CHECK(rows > 0 && D % V == 0, "clip_embed: bad shape rows=%d D=%d", rows, D);
+  hipStream_t st = (hipStream_t)stream;
+  int g = grid_for((size_t)rows * (D / V));
+  DISPATCH_T(dtype, (clip_embed_kernel<bf16_t><<<g, 256, 0, st>>>(ids, (const bf16_t*)table, (const bf16_t*)pos, (bf16_t*)out, rows, S, D, vocab)),
+             (clip_embed_kernel<float><<<g, 256, 0, st>>>(ids, (const float*)table, (const float*)pos, (float*)out, rows, S, D, vocab)));
+  SD_LAUNCH_CHECK("clip_embed");
+  return 0;
+}
+
+extern "C" int sdamd_concat_nhwc(const void* a, const void* b, void* out, long long pixels, int C1, int C2, int dtype,
+                                 void* stream) {
+  const int V = dtype == SDAMD_BF16 ? 8 : 4;
+  SD_CHECK(pixels > 0 && C1 % V == 0 && C2 % V == 0, "concat: bad shape");
+  hipStream_t st = (hipStream_t)stream;
+  int g = grid_for((size_t)pixels * ((C1 + C2) / V));
+  DISPATCH_T(dtype, (concat_kernel<bf16_t><<<g, 256, 0, st>>>((const bf16_t*)a, (const bf16_t*)b, (bf16_t*)out, (size_t)pixels, C1, C2)),
+             (concat_kernel<float><<<g, 256, 0, st>>>((const float*)a, (const float*)b, (float*)out, (size_t)pixels, C1, C2)));
+  SD_LAUNCH_CHECK("concat");
+  return 0;
+}
+
+extern "C" int sdamd_add(const void* a, const void* b, void* out, long long numel, int dtype, void* stream) {
+  const int V = dtype == SDAMD_BF16 ? 8 : 4;
+  SD_CHECK(numel > 0 && numel % V == 0, "add: numel=%lld must be a positive multiple of %d", numel, V);
+  hipStream_t st = (hipStream_t)stream;
+  int g = grid_for((size_t)numel / V);
+  DISPATCH_T(dtype, (add_kernel<bf16_t><<<g, 256, 0, st>>>((const bf16_t*)a, (const bf16_t*)b, (bf16_t*)out, (size_t)numel / V)),
+             (add_kernel<float><<<g, 256, 0, st>>>((const float*)a, (const float*)b, (float*)out, (size_t)numel / V)));
+  SD_LAUNCH_CHECK("add");
+  return 0;
+}
+
+extern "C" int sdamd_nchw_to_nhwc(const float* src, void* dst, int B, int C, int HW, int dtype, void* stream) {
+  SD_CHECK(B > 0 && C > 0 && HW > 0, "nchw_to_nhwc: empty input");
+  dim3 grid((HW + 31) / 32, (C + 31) / 32, B);
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH_T(dtype, (nchw_to_nhwc_kernel<bf16_t><<<grid, 256, 0, st>>>(src, (bf16_t*)dst, C, HW)),
+             (nchw_to_nhwc_kernel<float><<<grid, 256, 0, st>>>(src, (float*)dst, C, HW)));
+  SD_LAUNCH_CHECK("nchw_to_nhwc");
+  return 0;
+}
+
+extern "C" int sdamd_nhwc_to_nchw(const void* src, float* dst, int B, int C, int HW, int dtype, void* stream) {
+  SD_CHECK(B > 0 && C > 0 && HW > 0, "nhwc_to_nchw: empty input");
+  dim3 grid((HW + 31) / 32, (C + 31) / 32, B);
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH_T(dtype, (nhwc_to_nchw_kernel<bf16_t><<<grid, 256, 0, st>>>((const bf16_t*)src, dst, C, HW)),
+             (nhwc_to_nchw_kernel<float><<<grid, 256, 0, st>>>((const float*)src, dst, C, HW)));
+  SD_LAUNCH_CHECK("nhwc_to_nchw");
+  return 0;
+}
+
+extern "C" int sdamd_cast(const void* src, void* dst, long long n, int src_dtype, int dst_dtype, void* stream) {
+  SD_CHECK(n > 0, "cast: empty input");
+  hipStream_t st = (hipStream_t)stream;
+  int g = grid_for((size_t)n);
+  if (src_dtype == SDAMD_F32 && dst_dtype == SDAMD_BF16) cast_kernel<float, bf16_t><<<g, 256, 0, st>>>((const float*)src, (bf16_t*)dst, (size_t)n);
+  else if (src_dtype == SDAMD_BF16 && dst_dtype == SDAMD_F32) cast_kernel<bf16_t, float><<<g, 256, 0, st>>>((const bf16_t*)src, (float*)dst, (size_t)n);
+  else if (src_dtype == SDAMD_F32 && dst_dtype == SDAMD_F32) cast_kernel<float, float><<<g, 256, 0, st>>>((const float*)src, (float*)dst, (size_t)n);
+  else cast_kernel<bf16_t, bf16_t><<<g, 256, 0, st>>>((const bf16_t*)src, (bf16_t*)dst, (size_t)n);
+  SD_LAUNCH_CHECK("cast");
+  return 0;
+}
+
+extern "C" int sdamd_silu(const float* src, float* dst, long long n, void* stream) {
+  SD_CHECK(n > 0, "silu: empty input");
+  silu_kernel<<<grid_for((size_t)n), 256, 0, (hipStream_t)stream>>>(src, dst, (size_t)n);
+  SD_LAUNCH_CHECK("silu");
+  return 0;
+}
+
+extern "C" int sdamd_image_to_uint8(const float* src, unsigned char* dst, int B, int HW, void* stream) {
+  SD_CHECK(B > 0 && HW > 0, "image_to_uint8: empty input");
+  image_to_uint8_kernel<<<grid_for((size_t)B * HW * 3), 256, 0, (hipStream_t)stream>>>(src, dst, B, HW);
+  SD_LAUNCH_CHECK("image_to_uint8");
+  return 0;
+}
+
+extern "C" int sdamd_uint8_to_image(const unsigned char* src, float* dst, int B, int HW, void* stream) {
+  SD_CHECK(B > 0 && HW > 0, "uint8_to_image: empty input");
+  uint8_to_image_kernel<<<grid_for((size_t)B * HW * 3), 256, 0, (hipStream_t)stream>>>(src, dst, B, HW);
+  SD_LAUNCH_CHECK("uint8_to_image");
+  return 0;
+}
+
+extern "C" int sdamd_vae_post_quant(const float* x, float* y, const float* w, const float* b, int B, int HW, void* stream) {
+  SD_CHECK(B > 0 && HW > 0, "vae_post_quant: empty input");
+  vae_post_quant_kernel<<<grid_for((size_t)B * HW), 256, 0, (hipStream_t)stream>>>(x, y, w, b, B, HW);
+  SD_LAUNCH_CHECK("vae_post_quant");
+  return 0;
+}
+
+extern "C" int sdamd_vae_sample(const float* x, const float* noise, float* out, const float* w, const float* b, int B, int HW,
+                                void* stream) {
+  SD_CHECK(B > 0 && HW > 0, "vae_sample: empty input");
+  vae_sample_kernel<<<grid_for((size_t)B * HW), 256, 0, (hipStream_t)stream>>>(x, noise, out, w, b, B, HW);
+  SD_LAUNCH_CHECK("vae_sample");
+  return 0;
+}

@@ -1,0 +1,466 @@
+// MFMA GEMM / implicit-GEMM conv3x3 for gfx950 (bf16 and exact-f32 matrix cores).
+//
+//   out[m][n] = act( sum_k A[m][k] * W[n][k] + bias[n] + residual[m][n] )
+//
+// One kernel serves nn.Linear, conv1x1 (dense A rows) and conv3x3 over NHWC activations
+// (A rows gathered per output pixel and filter tap: stride 1/2, symmetric or bottom/right-only
+// padding, optional fused nearest-2x upsample of the input).  It replaces nn.Conv2d / nn.Linear
+// in diffusion.py:9-18,54,82-85,146,196-221,287, decoder.py:10-18,78-123, encoder.py:10-57,
+// clip.py:45-46 and the projections of attention.py:19-20,81-85.
+//
+// Tiling: 256 threads = 4 waves (2x2), block tile BM x BN, K-tile = 128 bytes per row
+// (64 bf16 / 32 f32).  Both operands are K-contiguous, staged through registers into LDS with a
+// 16-byte-chunk XOR swizzle (chunk ^= (row>>1)&7: conflict-free ds_read_b128 for the MFMA lane
+// groups), double-buffered with one barrier per K-tile.  MFMA "A" = weight rows, "B" =
+// activation rows, so each lane ends up with 4 consecutive output channels of one row: bias,
+// residual and the store are 8/16-byte vector accesses.
+//   bf16: v_mfma_f32_16x16x32_bf16, lane (r,q) feeds k = 8q..8q+7 of each 32-wide k-group.
+//   f32 : v_mfma_f32_16x16x4_f32 (bitwise an fmaf chain): lane (r,q) loads 4 consecutive k and
+//         issues 4 MFMAs; the k order is a permutation applied to both operands alike.
+#include "common.h"
+
+#define ACT_NONE 0
+#define ACT_QUICK_GELU 1
+#define ACT_SILU 2
+
+struct GemmArgs {
+  const void* A;     // dense: [M][lda]; conv: NHWC input [B][H][W][Cin]
+  const void* W;     // [N][ldw], K-contiguous (conv: [Cout][ky][kx][Cin])
+  void* C;           // [M][ldc]
+  const float* bias; // [N] or null
+  const void* R;     // residual [M][ldr] (same dtype as A) or null
+  int M, N, K;
+  int lda, ldw, ldc, ldr;
+  long long sA, sW, sC, sR;  // batch strides (elements), grid.y = batch
+  int act, out_f32;
+  // conv geometry (CONV only)
+  int H, Wd, Cin, Ho, Wo, stride, pad, ups;
+  int tiles_m, tiles_n;
+};
+
+template <typename T> struct Frag;
+template <> struct Frag<bf16_t> { typedef bf16x8_t type; };
+template <> struct Frag<float> { typedef f32x4_t type; };
+
+template <typename T>
+__device__ __forceinline__ void mma16(f32x4_t& acc, const typename Frag<T>::type& w, const typename Frag<T>::type& x);
+template <>
+__device__ __forceinline__ void mma16<bf16_t>(f32x4_t& acc, const bf16x8_t& w, const bf16x8_t& x) {
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, x, acc, 0, 0, 0);
+}
+template <>
+__device__ __forceinline__ void mma16<float>(f32x4_t& acc, const f32x4_t& w, const f32x4_t& x) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[e], x[e], acc, 0, 0, 0);
+}
+
+__device__ __forceinline__ int swz_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+
+template <typename T, int BM, int BN, bool CONV>
+__global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
+  constexpr int EPC = 16 / sizeof(T);  // elements per 16-byte chunk
+  constexpr int BKE = 8 * EPC;         // K elements per tile
+  constexpr int PA = BM / 32, PW = BN / 32;
+  constexpr int TM = BM / 32, TN = BN / 32;  // 16x16 tiles per wave along m / n
+  constexpr int STAGE = (BM + BN) * 128;
+  typedef typename Frag<T>::type frag_t;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  // XCD-aware tile order: blocks b, b+8, ... share an XCD (and its L2); give each XCD one
+  // contiguous run of tiles, n fastest, so a run re-uses its A rows and the whole W panel.
+  const int nwg = gridDim.x;
+  int bid = blockIdx.x;
+  {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int tn = bid % p.tiles_n, tm = bid / p.tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int batch = blockIdx.y;
+  const T* __restrict__ A = (const T*)p.A + (size_t)batch * p.sA;
+  const T* __restrict__ W = (const T*)p.W + (size_t)batch * p.sW;
+
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int ld_row = t >> 3, ld_chunk = t & 7;
+
+  // per-thread source rows
+  const T* wptr[PW];
+#pragma unroll
+  for (int i = 0; i < PW; ++i) {
+    int n = min(n0 + ld_row + 32 * i, p.N - 1);
+    wptr[i] = W + (size_t)n * p.ldw + ld_chunk * EPC;
+  }
+  const T* aptr[PA];       // dense: row pointer; conv: image base pointer
+  int ay[PA], ax[PA];      // conv: top-left input coordinate of the 3x3 window (upsampled grid)
+#pragma unroll
+  for (int i = 0; i < PA; ++i) {
+    int m = min(m0 + ld_row + 32 * i, p.M - 1);
+    if (CONV) {
+      int hw = p.Ho * p.Wo;
+      int n_img = m / hw, rem = m - n_img * hw;
+      int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+      ay[i] = oy * p.stride - p.pad;
+      ax[i] = ox * p.stride - p.pad;
+      aptr[i] = A + (size_t)n_img * p.H * p.Wd * p.Cin + ld_chunk * EPC;
+    } else {
+      aptr[i] = A + (size_t)m * p.lda + ld_chunk * EPC;
+      ay[i] = ax[i] = 0;
+    }
+  }
+  const int Hin = p.H << p.ups, Win = p.Wd << p.ups;
+
+  u32x4_t ra[PA], rw[PW];
+  int tap = 0, cc = 0;  // conv K position: filter tap and channel offset
+  auto issue_loads = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < PW; ++i) rw[i] = *reinterpret_cast<const u32x4_t*>(wptr[i] + k0);
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+      if (CONV) {
+        int ky = tap / 3, kx = tap - ky * 3;
+        int iy = ay[i] + ky, ix = ax[i] + kx;
+        bool ok = (unsigned)iy < (unsigned)Hin && (unsigned)ix < (unsigned)Win;
+        u32x4_t z = {0u, 0u, 0u, 0u};
+        if (ok) z = *reinterpret_cast<const u32x4_t*>(aptr[i] + ((size_t)(iy >> p.ups) * p.Wd + (ix >> p.ups)) * p.Cin + cc);
+        ra[i] = z;
+      } else {
+        ra[i] = *reinterpret_cast<const u32x4_t*>(aptr[i] + k0);
+      }
+    }
+    if (CONV) { cc += BKE; if (cc >= p.Cin) { cc = 0; ++tap; } }
+  };
+  auto write_lds = [&](int buf) {
+    char* sa = smem + buf * STAGE;
+    char* sw = sa + BM * 128;
+#pragma unroll
+    for (int i = 0; i < PA; ++i) *reinterpret_cast<u32x4_t*>(sa + swz_off(ld_row + 32 * i, ld_chunk)) = ra[i];
+#pragma unroll
+    for (int i = 0; i < PW; ++i) *reinterpret_cast<u32x4_t*>(sw + swz_off(ld_row + 32 * i, ld_chunk)) = rw[i];
+  };
+
+  f32x4_t acc[TN][TM];
+#pragma unroll
+  for (int j = 0; j < TN; ++j)
+#pragma unroll
+    for (int i = 0; i < TM; ++i) acc[j][i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  const int nk = p.K / BKE;
+  issue_loads(0);
+  write_lds(0);
+  __syncthreads();
+  const int r16 = lane & 15, q4 = lane >> 4;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) issue_loads((kt + 1) * BKE);
+    const char* sa = smem + cur * STAGE;
+    const char* sw = sa + BM * 128;
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      frag_t xf[TM], wf[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+        xf[i] = *reinterpret_cast<const frag_t*>(sa + swz_off(wm * (BM / 2) + i * 16 + r16, 4 * g + q4));
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        wf[j] = *reinterpret_cast<const frag_t*>(sw + swz_off(wn * (BN / 2) + j * 16 + r16, 4 * g + q4));
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int i = 0; i < TM; ++i) mma16<T>(acc[j][i], wf[j], xf[i]);
+    }
+    if (kt + 1 < nk) write_lds(cur ^ 1);
+    __syncthreads();
+  }
+
+  // epilogue: lane holds out[m][n..n+3]
+  const float* __restrict__ bias = p.bias;
+  const T* __restrict__ R = p.R ? (const T*)p.R + (size_t)batch * p.sR : nullptr;
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int m = m0 + wm * (BM / 2) + i * 16 + r16;
+    if (m >= p.M) continue;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = n0 + wn * (BN / 2) + j * 16 + q4 * 4;
+      if (n >= p.N) continue;
+      float v[4] = {acc[j][i][0], acc[j][i][1], acc[j][i][2], acc[j][i][3]};
+      if (bias) {
+        f32x4_t b = *reinterpret_cast<const f32x4_t*>(bias + n);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += b[r];
+      }
+      if (R) {
+        const T* rp = R + (size_t)m * p.ldr + n;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += Cvt<T>::ld(rp + r);
+      }
+      if (p.act == ACT_QUICK_GELU) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = quick_gelu_f(v[r]);
+      } else if (p.act == ACT_SILU) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = silu_f(v[r]);
+      }
+      if (p.out_f32 || sizeof(T) == 4) {
+        float* cp = (float*)p.C + (size_t)batch * p.sC + (size_t)m * p.ldc + n;
+        *reinterpret_cast<f32x4_t*>(cp) = (f32x4_t){v[0], v[1], v[2], v[3]};
+      } else {
+        bf16_t* cp = (bf16_t*)p.C + (size_t)batch * p.sC + (size_t)m * p.ldc + n;
+        u32x2_t o = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+        *reinterpret_cast<u32x2_t*>(cp) = o;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// small-channel convolutions at the model boundaries (FLOPs negligible, VALU kernels)
+// ---------------------------------------------------------------------------------------------
+// 3x3, pad 1, stride 1, tiny Cin (3, 4): input NCHW f32, output NHWC T.  Weights [ky][kx][ci][Cout] f32.
+// One thread = one output pixel x 4 output channels.
+template <typename T, int CIN>
+__global__ __launch_bounds__(256) void conv3x3_cin_small_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                const float* __restrict__ bias, T* __restrict__ y, int B,
+                                                                int H, int Wd, int Cout) {
+  const int q = Cout / 4;
+  const size_t total = (size_t)B * H * Wd * q;
+  for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+    int cq = (int)(idx % q);
+    size_t pix = idx / q;
+    int xw = (int)(pix % Wd);
+    int yh = (int)((pix / Wd) % H);
+    int n = (int)(pix / ((size_t)Wd * H));
+    f32x4_t acc = *reinterpret_cast<const f32x4_t*>(bias + cq * 4);
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      int iy = yh + ky - 1;
+      if ((unsigned)iy >= (unsigned)H) continue;
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        int ix = xw + kx - 1;
+        if ((unsigned)ix >= (unsigned)Wd) continue;
+#pragma unroll
+        for (int ci = 0; ci < CIN; ++ci) {
+          float v = x[(((size_t)n * CIN + ci) * H + iy) * Wd + ix];
+          f32x4_t ww = *reinterpret_cast<const f32x4_t*>(w + ((size_t)((ky * 3 + kx) * CIN + ci)) * Cout + cq * 4);
+          acc += v * ww;
+        }
+      }
+    }
+    T* dst = y + pix * Cout + cq * 4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Cvt<T>::st(dst + r, acc[r]);
+  }
+}
+
+// 3x3, pad 1, stride 1, tiny Cout (3, 4, 8): input NHWC T, output NCHW f32.
+// Weights [tap][Cin/V][COUT][V] in T.  8 lanes share one output pixel (each takes every 8th
+// 16-byte channel chunk: 128 contiguous bytes per pixel per instruction), then a shuffle reduce.
+template <typename T, int COUT>
+__global__ __launch_bounds__(256) void conv3x3_cout_small_kernel(const T* __restrict__ x, const T* __restrict__ w,
+                                                                 const float* __restrict__ bias, float* __restrict__ y,
+                                                                 int B, int H, int Wd, int Cin) {
+  constexpr int V = 16 / sizeof(T);
+  const int sub = threadIdx.x & 7;
+  const int cvs = Cin / V;
+  const size_t npix = (size_t)B * H * Wd;
+  const size_t pix0 = ((size_t)blockIdx.x * 256 + threadIdx.x) >> 3;
+  const size_t pstride = ((size_t)gridDim.x * 256) >> 3;
+  for (size_t pixi = pix0; pixi < ((npix + 31) / 32) * 32; pixi += pstride) {  // keep 8-lane groups converged
+    const bool live = pixi < npix;
+    const size_t pix = live ? pixi : npix - 1;
+    int xw = (int)(pix % Wd);
+    int yh = (int)((pix / Wd) % H);
+    int n = (int)(pix / ((size_t)Wd * H));
+    float acc[COUT];
+#pragma unroll
+    for (int o = 0; o < COUT; ++o) acc[o] = 0.f;
+    for (int ky = 0; ky < 3; ++ky) {
+      int iy = yh + ky - 1;
+      if ((unsigned)iy >= (unsigned)H) continue;
+      for (int kx = 0; kx < 3; ++kx) {
+        int ix = xw + kx - 1;
+        if ((unsigned)ix >= (unsigned)Wd) continue;
+        const T* src = x + (((size_t)n * H + iy) * Wd + ix) * Cin;
+        const T* wt = w + (size_t)(ky * 3 + kx) * cvs * COUT * V;
+        for (int cv = sub; cv < cvs; cv += 8) {
+          float v[V];
+          load_vec<T>(src + (size_t)cv * V, v);
+#pragma unroll
+          for (int o = 0; o < COUT; ++o) {
+            float ww[V];
+            load_vec<T>(wt + ((size_t)cv * COUT + o) * V, ww);
+#pragma unroll
+            for (int j = 0; j < V; ++j) acc[o] += v[j] * ww[j];
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int o = 0; o < COUT; ++o) {
+      float a = acc[o];
+      a += __shfl_xor(a, 1, 64);
+      a += __shfl_xor(a, 2, 64);
+      a += __shfl_xor(a, 4, 64);
+      acc[o] = a;
+    }
+    if (live && sub == 0) {
+#pragma unroll
+      for (int o = 0; o < COUT; ++o) y[(((size_t)n * COUT + o) * H + yh) * Wd + xw] = acc[o] + bias[o];
+    }
+  }
+}
+
+// batched 2-D transpose of T: src [batch][rows][ld_src] (first `cols` columns) -> dst [batch][cols][rows]
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_kernel(const T* __restrict__ src, T* __restrict__ dst, int rows, int cols,
+                                                        int ld_src, long long s_src, long long s_dst) {
+  __shared__ T tile[32][33];
+  const int b = blockIdx.z, r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int i = ty; i < 32; i += 8) {
+    int r = r0 + i, c = c0 + tx;
+    if (r < rows && c < cols) tile[i][tx] = src[(size_t)b * s_src + (size_t)r * ld_src + c];
+  }
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8) {
+    int c = c0 + i, r = r0 + tx;
+    if (r < rows && c < cols) dst[(size_t)b * s_dst + (size_t)c * rows + r] = tile[tx][i];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+template <typename T, int BM, int BN, bool CONV>
+static int launch_gemm(GemmArgs& a, int batch, hipStream_t st) {
+  a.tiles_m = (a.M + BM - 1) / BM;
+  a.tiles_n = (a.N + BN - 1) / BN;
+  const int lds = 2 * (BM + BN) * 128;
+  static bool attr_set = false;
+  if (!attr_set && lds > 48 * 1024) {
+    (void)hipFuncSetAttribute((const void*)gemm_kernel<T, BM, BN, CONV>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_set = true;
+  }
+  dim3 grid(a.tiles_m * a.tiles_n, batch);
+  gemm_kernel<T, BM, BN, CONV><<<grid, 256, lds, st>>>(a);
+  SD_LAUNCH_CHECK("gemm");
+  return 0;
+}
+
+template <typename T, bool CONV>
+static int pick_tile(GemmArgs& a, int batch, hipStream_t st) {
+  // Prefer 128x128; drop to smaller tiles when the grid would leave most of the 256 CUs idle
+  // or when N wastes a large part of a 128-wide tile.
+  auto blocks = [&](int bm, int bn) { return (long long)((a.M + bm - 1) / bm) * ((a.N + bn - 1) / bn) * batch; };
+  const bool n64 = (a.N % 128) != 0 && (a.N % 128) <= 64;  // e.g. N = 320: 5 x 64 exact, 128 wastes 17 %
+  if (!n64 && blocks(128, 128) >= 512) return launch_gemm<T, 128, 128, CONV>(a, batch, st);
+  if (blocks(128, 64) >= 512) return launch_gemm<T, 128, 64, CONV>(a, batch, st);
+  if (a.M > 64 && blocks(128, 64) >= 256) return launch_gemm<T, 128, 64, CONV>(a, batch, st);
+  return launch_gemm<T, 64, 64, CONV>(a, batch, st);
+}
+
+static int check_common(const GemmArgs& a, int dtype, const char* what) {
+  const int esz = dtype == SDAMD_BF16 ? 2 : 4;
+  const int bke = 128 / esz;
+  SD_CHECK(dtype == SDAMD_BF16 || dtype == SDAMD_F32, "%s: bad dtype %d", what, dtype);
+  SD_CHECK(a.M > 0 && a.N > 0 && a.K > 0, "%s: empty problem M=%d N=%d K=%d", what, a.M, a.N, a.K);
+  SD_CHECK(a.K % bke == 0, "%s: K=%d must be a multiple of %d", what, a.K, bke);
+  SD_CHECK(a.N % 16 == 0, "%s: N=%d must be a multiple of 16", what, a.N);
+  SD_CHECK(a.A && a.W && a.C, "%s: null pointer", what);
+  SD_CHECK(((uintptr_t)a.A % 16) == 0 && ((uintptr_t)a.W % 16) == 0 && ((uintptr_t)a.C % 16) == 0, "%s: pointers must be 16-byte aligned", what);
+  SD_CHECK((a.ldw * esz) % 16 == 0 && a.ldc % 4 == 0, "%s: leading dimensions must keep 16-byte alignment", what);
+  return 0;
+}
+
+extern "C" int sdamd_gemm(const void* A, const void* W, void* C, const float* bias, const void* residual, int M, int N, int K,
+                          int lda, int ldw, int ldc, int ldr, int batch, long long strideA, long long strideW,
+                          long long strideC, long long strideR, int act, int dtype, int out_f32, void* stream) {
+  GemmArgs a = {};
+  a.A = A; a.W = W; a.C = C; a.bias = bias; a.R = residual;
+  a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldw = ldw; a.ldc = ldc; a.ldr = ldr;
+  a.sA = strideA; a.sW = strideW; a.sC = strideC; a.sR = strideR;
+  a.act = act; a.out_f32 = out_f32;
+  if (int e = check_common(a, dtype, "gemm")) return e;
+  const int esz = dtype == SDAMD_BF16 ? 2 : 4;
+  SD_CHECK((lda * esz) % 16 == 0 && lda >= K && ldw >= K && ldc >= N, "gemm: bad leading dimensions lda=%d ldw=%d ldc=%d", lda, ldw, ldc);
+  SD_CHECK(batch >= 1, "gemm: batch=%d", batch);
+  SD_CHECK(!residual || ldr >= N, "gemm: ldr=%d < N", ldr);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == SDAMD_BF16) return pick_tile<bf16_t, false>(a, batch, st);
+  return pick_tile<float, false>(a, batch, st);
+}
+
+// conv3x3 over NHWC.  pad_mode 0: symmetric pad 1 (diffusion.py / decoder.py convs);
+// pad_mode 1: pad bottom/right only (encoder.py:65-66 F.pad(0,1,0,1) + stride-2 pad-0 conv).
+// upsample=1 reads the input through a nearest 2x upsample (diffusion.py:148-150, decoder.py:90-111).
+extern "C" int sdamd_conv3x3(const void* x, const void* w, void* y, const float* bias, const void* residual, int B, int H,
+                             int Wd, int Cin, int Cout, int stride, int pad_mode, int upsample, int act, int dtype,
+                             int out_f32, void* stream) {
+  SD_CHECK(stride == 1 || stride == 2, "conv3x3: stride=%d", stride);
+  SD_CHECK(pad_mode == 0 || pad_mode == 1, "conv3x3: pad_mode=%d", pad_mode);
+  SD_CHECK(upsample == 0 || upsample == 1, "conv3x3: upsample=%d", upsample);
+  SD_CHECK(B > 0 && H > 0 && Wd > 0, "conv3x3: empty input");
+  const int Hin = H << upsample, Win = Wd << upsample;
+  const int pad = pad_mode == 0 ? 1 : 0;
+  const int Ho = pad_mode == 0 ? (Hin + 2 - 3) / stride + 1 : (Hin + 1 - 3) / stride + 1;
+  const int Wo = pad_mode == 0 ? (Win + 2 - 3) / stride + 1 : (Win + 1 - 3) / stride + 1;
+  GemmArgs a = {};
+  a.A = x; a.W = w; a.C = y; a.bias = bias; a.R = residual;
+  a.M = B * Ho * Wo; a.N = Cout; a.K = 9 * Cin;
+  a.lda = 0; a.ldw = 9 * Cin; a.ldc = Cout; a.ldr = Cout;
+  a.act = act; a.out_f32 = out_f32;
+  a.H = H; a.Wd = Wd; a.Cin = Cin; a.Ho = Ho; a.Wo = Wo; a.stride = stride; a.pad = pad; a.ups = upsample;
+  if (int e = check_common(a, dtype, "conv3x3")) return e;
+  const int bke = dtype == SDAMD_BF16 ? 64 : 32;
+  SD_CHECK(Cin % bke == 0, "conv3x3: Cin=%d must be a multiple of %d (use the small-channel kernels)", Cin, bke);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == SDAMD_BF16) return pick_tile<bf16_t, true>(a, 1, st);
+  return pick_tile<float, true>(a, 1, st);
+}
+
+extern "C" int sdamd_conv3x3_cin_small(const float* x_nchw, const float* w_tap_ci_co, const float* bias, void* y_nhwc, int B,
+                                       int H, int Wd, int Cin, int Cout, int dtype, void* stream) {
+  SD_CHECK(Cin == 3 || Cin == 4, "conv3x3_cin_small: Cin=%d (3 or 4)", Cin);
+  SD_CHECK(Cout % 4 == 0 && B > 0 && H > 0 && Wd > 0, "conv3x3_cin_small: bad shape");
+  hipStream_t st = (hipStream_t)stream;
+  size_t total = (size_t)B * H * Wd * (Cout / 4);
+  int g = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+#define CS(TT, CI) conv3x3_cin_small_kernel<TT, CI><<<g, 256, 0, st>>>(x_nchw, w_tap_ci_co, bias, (TT*)y_nhwc, B, H, Wd, Cout)
+  if (dtype == SDAMD_BF16) { if (Cin == 3) CS(bf16_t, 3); else CS(bf16_t, 4); }
+  else { if (Cin == 3) CS(float, 3); else CS(float, 4); }
+#undef CS
+  SD_LAUNCH_CHECK("conv3x3_cin_small");
+  return 0;
+}
+
+extern "C" int sdamd_conv3x3_cout_small(const void* x_nhwc, const void* w_packed, const float* bias, float* y_nchw, int B,
+                                        int H, int Wd, int Cin, int Cout, int dtype, void* stream) {
+  const int V = dtype == SDAMD_BF16 ? 8 : 4;
+  SD_CHECK(Cout == 3 || Cout == 4 || Cout == 8, "conv3x3_cout_small: Cout=%d (3, 4 or 8)", Cout);
+  SD_CHECK(Cin % V == 0 && B > 0 && H > 0 && Wd > 0, "conv3x3_cout_small: bad shape");
+  hipStream_t st = (hipStream_t)stream;
+  size_t npix = (size_t)B * H * Wd;
+  size_t blocks = (npix * 8 + 255) / 256;
+  int g = (int)(blocks > 16384 ? 16384 : blocks);
+#define CS(TT, CO) conv3x3_cout_small_kernel<TT, CO><<<g, 256, 0, st>>>((const TT*)x_nhwc, (const TT*)w_packed, bias, y_nchw, B, H, Wd, Cin)
+  if (dtype == SDAMD_BF16) { if (Cout == 3) CS(bf16_t, 3); else if (Cout == 4) CS(bf16_t, 4); else CS(bf16_t, 8); }
+  else { if (Cout == 3) CS(float, 3); else if (Cout == 4) CS(float, 4); else CS(float, 8); }
+#undef CS
+  SD_LAUNCH_CHECK("conv3x3_cout_small");
+  return 0;
+}
+
+extern "C" int sdamd_transpose(const void* src, void* dst, int batch, int rows, int cols, int ld_src, long long stride_src,
+                               long long stride_dst, int dtype, void* stream) {
+  SD_CHECK(batch > 0 && rows > 0 && cols > 0 && ld_src >= cols, "transpose: bad shape");
+  dim3 grid((cols + 31) / 32, (rows + 31) / 32, batch);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == SDAMD_BF16)
+    transpose_kernel<bf16_t><<<grid, 256, 0, st>>>((const bf16_t*)src, (bf16_t*)dst, rows, cols, ld_src, stride_src, stride_dst);
+  else
+    transpose_kernel<float><<<grid, 256, 0, st>>>((const float*)src, (float*)dst, rows, cols, ld_src, stride_src, stride_dst);
+  SD_LAUNCH_CHECK("transpose");
+  return 0;
+}

@@ -1,0 +1,287 @@
+// GroupNorm(+SiLU) over NHWC and LayerNorm: HBM-bound kernels with wavefront reductions.
+// Replaces the eager chains diffusion.py:26-28,38-40,93,292-294; decoder.py:25-30,49,118-120;
+// clip.py:54,63,95 of the reference.  Statistics are accumulated in f64 (deterministic order,
+// no atomics) so fp32 results stay well inside the 1e-4 budget of the whole UNet.
+#include "common.h"
+
+// ---------------------------------------------------------------------------------------------
+// GroupNorm stats: grid (nblk, B), 256 threads.  A block walks a contiguous range of pixels of
+// image n; thread t owns channel-vector cv = t % tpp (+ i*tpp for i < nchunk) and pixel lane
+// t / tpp, so the channel (hence the group) of every register accumulator is fixed.
+// Per-block partial sums go to ws[n][blk][32][2] (double); gn_apply finishes the reduction.
+// ---------------------------------------------------------------------------------------------
+constexpr int GN_THREADS = 256;
+constexpr int GN_MAXCHUNK = 4;
+
+template <typename T>
+__global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const T* __restrict__ x, double* __restrict__ ws,
+                                                              int HW, int C, int tpp, int nchunk, int pix_per_blk) {
+  constexpr int V = 16 / sizeof(T);
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double* part = reinterpret_cast<double*>(smem);  // [pif][C][2]
+  const int n = blockIdx.y, blk = blockIdx.x, nblk = gridDim.x;
+  const int t = threadIdx.x;
+  const int pif = GN_THREADS / tpp;  // pixels in flight
+  const int pl = t / tpp, cvt = t % tpp;
+  const int p0 = blk * pix_per_blk;
+  const int p1 = min(HW, p0 + pix_per_blk);
+  double s[GN_MAXCHUNK][V], q[GN_MAXCHUNK][V];
+#pragma unroll
+  for (int i = 0; i < GN_MAXCHUNK; ++i)
+#pragma unroll
+    for (int j = 0; j < V; ++j) { s[i][j] = 0.0; q[i][j] = 0.0; }
+  if (pl < pif) {
+    const T* base = x + (size_t)n * HW * C;
+    for (int p = p0 + pl; p < p1; p += pif) {
+      const T* row = base + (size_t)p * C;
+#pragma unroll
+      for (int i = 0; i < GN_MAXCHUNK; ++i) {
+        if (i < nchunk) {
+          float v[V];
+          load_vec<T>(row + (size_t)(cvt + i * tpp) * V, v);
+#pragma unroll
+          for (int j = 0; j < V; ++j) { double d = (double)v[j]; s[i][j] += d; q[i][j] += d * d; }
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < GN_MAXCHUNK; ++i) {
+      if (i < nchunk) {
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+          int c = (cvt + i * tpp) * V + j;
+          part[((size_t)pl * C + c) * 2 + 0] = s[i][j];
+          part[((size_t)pl * C + c) * 2 + 1] = q[i][j];
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // 8 threads per group, fixed summation order -> deterministic
+  const int g = t >> 3, sub = t & 7;
+  const int cpg = C / 32;
+  const int nent = pif * cpg;
+  double ss = 0.0, qq = 0.0;
+  for (int e = sub; e < nent; e += 8) {
+    int ppl = e / cpg, c = g * cpg + e % cpg;
+    ss += part[((size_t)ppl * C + c) * 2 + 0];
+    qq += part[((size_t)ppl * C + c) * 2 + 1];
+  }
+#pragma unroll
+  for (int o = 4; o > 0; o >>= 1) { ss += __shfl_xor(ss, o, 64); qq += __shfl_xor(qq, o, 64); }
+  if (sub == 0) {
+    double* dst = ws + (((size_t)n * nblk + blk) * 32 + g) * 2;
+    dst[0] = ss; dst[1] = qq;
+  }
+}
+
+// GroupNorm apply (+ optional SiLU): grid (nblk2, B).  Each block first reduces the nblk_stats
+// partials of image n into mean/rstd for its 32 groups, then streams its pixel range.
+template <typename T>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, T* __restrict__ y,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       const double* __restrict__ ws, int nblk_stats, int HW, int C,
+                                                       float eps, int silu, int pix_per_blk) {
+  constexpr int V = 16 / sizeof(T);
+  __shared__ float s_mean[32], s_rstd[32];
+  const int n = blockIdx.y;
+  const int t = threadIdx.x;
+  const int cpg = C / 32;
+  if (t < 32) {
+    double ss = 0.0, qq = 0.0;
+    for (int b = 0; b < nblk_stats; ++b) {
+      const double* src = ws + (((size_t)n * nblk_stats + b) * 32 + t) * 2;
+      ss += src[0]; qq += src[1];
+    }
+    double cnt = (double)HW * cpg;
+    double mean = ss / cnt;
+    double var = qq / cnt - mean * mean;
+    if (var < 0.0) var = 0.0;
+    s_mean[t] = (float)mean;
+    s_rstd[t] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+  __syncthreads();
+  const int vpp = C / V;  // vectors per pixel
+  const int p0 = blockIdx.x * pix_per_blk;
+  const int p1 = min(HW, p0 + pix_per_blk);
+  const size_t img = (size_t)n * HW * C;
+  const int nvec = (p1 - p0) * vpp;
+  for (int i = t; i < nvec; i += 256) {
+    int p = p0 + i / vpp, cv = i % vpp;
+    size_t off = img + (size_t)p * C + (size_t)cv * V;
+    float v[V];
+    load_vec<T>(x + off, v);
+    int g = (cv * V) / cpg, rem = cv * V - g * cpg;
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      int c = cv * V + j;
+      float r = (v[j] - s_mean[g]) * s_rstd[g] * gamma[c] + beta[c];
+      v[j] = silu ? silu_f(r) : r;
+      if (++rem == cpg) { rem = 0; ++g; }
+    }
+    store_vec<T>(y + off, v);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// LayerNorm over the last dim: one wave per row, the row lives in registers (C <= 64*5*V).
+// ---------------------------------------------------------------------------------------------
+constexpr int LN_MAXIT = 5;
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x, T* __restrict__ y,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        int rows, int C, float eps) {
+  constexpr int V = 16 / sizeof(T);
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int nvec = C / V;
+  const T* xr = x + (size_t)row * C;
+  float v[LN_MAXIT][V];
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAXIT; ++i) {
+    int cv = lane + i * 64;
+    if (cv < nvec) {
+      load_vec<T>(xr + (size_t)cv * V, v[i]);
+#pragma unroll
+      for (int j = 0; j < V; ++j) sum += v[i][j];
+    }
+  }
+  const float mean = wave_sum(sum) / (float)C;
+  float sq = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAXIT; ++i) {
+    int cv = lane + i * 64;
+    if (cv < nvec) {
+#pragma unroll
+      for (int j = 0; j < V; ++j) { float d = v[i][j] - mean; sq += d * d; }
+    }
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum(sq) / (float)C + eps);
+  T* yr = y + (size_t)row * C;
+#pragma unroll
+  for (int i = 0; i < LN_MAXIT; ++i) {
+    int cv = lane + i * 64;
+    if (cv < nvec) {
+      float o[V];
+#pragma unroll
+      for (int j = 0; j < V; ++j) {
+        int c = cv * V + j;
+        o[j] = (v[i][j] - mean) * rstd * gamma[c] + beta[c];
+      }
+      store_vec<T>(yr + (size_t)cv * V, o);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Row softmax with scale (for the unfused d_head=512 VAE attention): one block per row,
+// in: f32 scores [rows][n], out: T probabilities [rows][n].
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ s, T* __restrict__ p, int n,
+                                                           float scale) {
+  __shared__ float red[4];
+  const float* sr = s + (size_t)blockIdx.x * n;
+  T* pr = p + (size_t)blockIdx.x * n;
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  float m = -3.0e38f;
+  for (int i = t; i < n; i += 256) m = fmaxf(m, sr[i]);
+  m = wave_max(m);
+  if (lane == 0) red[w] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  __syncthreads();
+  float sum = 0.f;
+  for (int i = t; i < n; i += 256) sum += expf((sr[i] - m) * scale);
+  sum = wave_sum(sum);
+  if (lane == 0) red[w] = sum;
+  __syncthreads();
+  sum = (red[0] + red[1]) + (red[2] + red[3]);
+  const float inv = 1.0f / sum;
+  for (int i = t; i < n; i += 256) Cvt<T>::st(pr + i, expf((sr[i] - m) * scale) * inv);
+}
+
+// ---------------------------------------------------------------------------------------------
+// host entry points
+// ---------------------------------------------------------------------------------------------
+static int gn_geometry(int C, int V, int* tpp, int* nchunk) {
+  int cvs = C / V;
+  int nc = (cvs + GN_THREADS - 1) / GN_THREADS;
+  while (nc <= GN_MAXCHUNK && cvs % nc != 0) ++nc;
+  if (nc > GN_MAXCHUNK) return -1;
+  *nchunk = nc;
+  *tpp = cvs / nc;
+  return 0;
+}
+
+extern "C" size_t sdamd_groupnorm_ws_bytes(int B) { return (size_t)B * 64 * 32 * 2 * sizeof(double); }
+
+extern "C" int sdamd_groupnorm_nhwc(const void* x, void* y, const float* gamma, const float* beta, void* ws, int B,
+                                    int HW, int C, float eps, int silu, int dtype, void* stream) {
+  const int V = dtype == SDAMD_BF16 ? 8 : 4;
+  SD_CHECK(C % 32 == 0 && C % V == 0, "groupnorm: C=%d must be a multiple of 32 and of the 16-byte vector", C);
+  SD_CHECK(B > 0 && HW > 0, "groupnorm: empty input B=%d HW=%d", B, HW);
+  int tpp, nchunk;
+  SD_CHECK(gn_geometry(C, V, &tpp, &nchunk) == 0, "groupnorm: unsupported C=%d", C);
+  const int pif = GN_THREADS / tpp;
+  size_t lds = (size_t)pif * C * 2 * sizeof(double);
+  SD_CHECK(lds <= 160 * 1024, "groupnorm: C=%d needs %zu B of LDS", C, lds);
+  // stats blocks per image: enough to fill the chip, at most 64 (ws size), >= 1 pixel sweep each
+  int want = (2048 + B - 1) / B;
+  int nblk = HW / (pif * 4);
+  if (nblk > want) nblk = want;
+  if (nblk > 64) nblk = 64;
+  if (nblk < 1) nblk = 1;
+  int ppb = (HW + nblk - 1) / nblk;
+  nblk = (HW + ppb - 1) / ppb;
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid(nblk, B);
+  if (dtype == SDAMD_BF16) {
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)gn_stats_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    gn_stats_kernel<bf16_t><<<grid, GN_THREADS, lds, st>>>((const bf16_t*)x, (double*)ws, HW, C, tpp, nchunk, ppb);
+  } else {
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)gn_stats_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    gn_stats_kernel<float><<<grid, GN_THREADS, lds, st>>>((const float*)x, (double*)ws, HW, C, tpp, nchunk, ppb);
+  }
+  SD_LAUNCH_CHECK("gn_stats");
+  // apply: ~2K vectors (32 KB) per block
+  int vpp = C / V;
+  int ppb2 = (2048 + vpp - 1) / vpp;
+  if (ppb2 < 1) ppb2 = 1;
+  int nblk2 = (HW + ppb2 - 1) / ppb2;
+  dim3 grid2(nblk2, B);
+  if (dtype == SDAMD_BF16)
+    gn_apply_kernel<bf16_t><<<grid2, 256, 0, st>>>((const bf16_t*)x, (bf16_t*)y, gamma, beta, (const double*)ws, nblk, HW, C, eps, silu, ppb2);
+  else
+    gn_apply_kernel<float><<<grid2, 256, 0, st>>>((const float*)x, (float*)y, gamma, beta, (const double*)ws, nblk, HW, C, eps, silu, ppb2);
+  SD_LAUNCH_CHECK("gn_apply");
+  return 0;
+}
+
+extern "C" int sdamd_layernorm(const void* x, void* y, const float* gamma, const float* beta, int rows, int C, float eps,
+                               int dtype, void* stream) {
+  const int V = dtype == SDAMD_BF16 ? 8 : 4;
+  SD_CHECK(C % V == 0 && C / V <= 64 * LN_MAXIT, "layernorm: unsupported C=%d", C);
+  SD_CHECK(rows > 0, "layernorm: empty input");
+  hipStream_t st = (hipStream_t)stream;
+  int grid = (rows + 3) / 4;
+  if (dtype == SDAMD_BF16)
+    layernorm_kernel<bf16_t><<<grid, 256, 0, st>>>((const bf16_t*)x, (bf16_t*)y, gamma, beta, rows, C, eps);
+  else
+    layernorm_kernel<float><<<grid, 256, 0, st>>>((const float*)x, (float*)y, gamma, beta, rows, C, eps);
+  SD_LAUNCH_CHECK("layernorm");
+  return 0;
+}
+
+extern "C" int sdamd_softmax_rows(const float* scores, void* probs, int rows, int n, float scale, int dtype, void* stream) {
+  SD_CHECK(rows > 0 && n > 0, "softmax_rows: empty input");
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == SDAMD_BF16)
+    softmax_rows_kernel<bf16_t><<<rows, 256, 0, st>>>(scores, (bf16_t*)probs, n, scale);
+  else
+    softmax_rows_kernel<float><<<rows, 256, 0, st>>>(scores, (float*)probs, n, scale);
+  SD_LAUNCH_CHECK("softmax_rows");
+  return 0;
+}

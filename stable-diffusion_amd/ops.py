@@ -1,0 +1,381 @@
+"""Host-side operators: torch tensors in, one C-ABI launch each (include/sdamd.h).
+
+PyTorch is only the tensor host here (device memory, streams).  Every function checks the
+shapes/dtypes the kernels assume before launching, uses torch's current HIP stream (so the
+launches are capturable into a hipGraph) and never falls back to torch eager math.
+
+Activation layout is NHWC / token-major: [B, H, W, C] or [B, S, C], float32 or bfloat16.
+"""
+import math
+
+import torch
+
+from . import _lib
+
+F32, BF16 = 0, 1
+ACT_NONE, ACT_QUICK_GELU, ACT_SILU = 0, 1, 2
+
+
+def _code(dtype):
+    if dtype == torch.float32:
+        return F32
+    if dtype == torch.bfloat16:
+        return BF16
+    raise TypeError(f"sd_amd kernels compute in float32 or bfloat16, got {dtype}")
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dev(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise _lib.SdamdError("sd_amd ops need tensors on the HIP device (no CPU fallback)")
+
+
+def _p(t):
+    return 0 if t is None else t.data_ptr()
+
+
+_gn_ws = {}
+
+
+def _groupnorm_ws(batch, device):
+    key = (device, torch.cuda.current_stream().cuda_stream)
+    need = _lib.lib().sdamd_groupnorm_ws_bytes(batch)
+    ws = _gn_ws.get(key)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(max(need, 1 << 20), dtype=torch.uint8, device=device)
+        _gn_ws[key] = ws
+    return ws
+
+
+# ------------------------------------------------------------------ sampler
+def cfg_ddpm_step(latents, eps, noise, coef, step, cfg_scale, do_cfg=True, step_ptr=None):
+    """In-place on ``latents`` [B,4,h,w] f32; eps [2B,4,h,w] f32 ([pos..., neg...])."""
+    _dev(latents, eps, coef)
+    B = latents.shape[0]
+    n = latents[0].numel()
+    assert latents.dtype == torch.float32 and eps.dtype == torch.float32 and coef.dtype == torch.float32
+    assert latents.is_contiguous() and eps.is_contiguous() and coef.is_contiguous()
+    assert eps.numel() == (2 if do_cfg else 1) * B * n, (eps.shape, latents.shape)
+    assert coef.dim() == 2 and coef.shape[1] == 8
+    if noise is not None:
+        assert noise.dtype == torch.float32 and noise.is_contiguous() and noise.numel() == coef.shape[0] * B * n
+    if step_ptr is not None:
+        assert step_ptr.dtype == torch.int32 and step_ptr.is_cuda
+    else:
+        assert 0 <= step < coef.shape[0]
+    _lib.check(_lib.lib().sdamd_cfg_ddpm_step(_p(latents), _p(eps), _p(noise), _p(coef), _p(step_ptr), int(step),
+                                              float(cfg_scale), int(do_cfg), B, n, _stream()))
+    return latents
+
+
+def counter_add(counter, delta=1):
+    assert counter.dtype == torch.int32 and counter.is_cuda
+    _lib.check(_lib.lib().sdamd_counter_add(_p(counter), int(delta), _stream()))
+
+
+def add_noise(x, noise, sqrt_abar, sqrt_one_minus_abar):
+    _dev(x, noise)
+    assert x.dtype == torch.float32 and noise.dtype == torch.float32 and x.shape == noise.shape
+    x, noise = x.contiguous(), noise.contiguous()
+    out = torch.empty_like(x)
+    _lib.check(_lib.lib().sdamd_add_noise(_p(out), _p(x), _p(noise), float(sqrt_abar), float(sqrt_one_minus_abar),
+                                          x.numel(), _stream()))
+    return out
+
+
+def gather_row(dst, table, step=0, step_ptr=None):
+    _dev(dst, table)
+    assert dst.dtype == torch.float32 and table.dtype == torch.float32 and table.dim() == 2
+    assert dst.numel() == table.shape[1] and dst.is_contiguous() and table.is_contiguous()
+    if step_ptr is None:
+        assert 0 <= step < table.shape[0]
+    _lib.check(_lib.lib().sdamd_gather_row(_p(dst), _p(table), _p(step_ptr), int(step), table.shape[1], _stream()))
+    return dst
+
+
+# ------------------------------------------------------------------ norms
+def groupnorm(x, gamma, beta, eps, silu):
+    """x [B, ..., C] NHWC; 32 groups."""
+    _dev(x, gamma, beta)
+    assert x.is_contiguous() and gamma.dtype == torch.float32 and beta.dtype == torch.float32
+    B, C = x.shape[0], x.shape[-1]
+    HW = x.numel() // (B * C)
+    assert gamma.numel() == C and beta.numel() == C
+    y = torch.empty_like(x)
+    ws = _groupnorm_ws(B, x.device)
+    _lib.check(_lib.lib().sdamd_groupnorm_nhwc(_p(x), _p(y), _p(gamma), _p(beta), _p(ws), B, HW, C, float(eps), int(silu),
+                                               _code(x.dtype), _stream()))
+    return y
+
+
+def layernorm(x, gamma, beta, eps=1e-5):
+    _dev(x, gamma, beta)
+    assert x.is_contiguous() and gamma.dtype == torch.float32 and beta.dtype == torch.float32
+    C = x.shape[-1]
+    assert gamma.numel() == C and beta.numel() == C
+    y = torch.empty_like(x)
+    _lib.check(_lib.lib().sdamd_layernorm(_p(x), _p(y), _p(gamma), _p(beta), x.numel() // C, C, float(eps), _code(x.dtype),
+                                          _stream()))
+    return y
+
+
+def softmax_rows(scores, scale, out_dtype):
+    _dev(scores)
+    assert scores.dtype == torch.float32 and scores.is_contiguous()
+    n = scores.shape[-1]
+    out = torch.empty(scores.shape, dtype=out_dtype, device=scores.device)
+    _lib.check(_lib.lib().sdamd_softmax_rows(_p(scores), _p(out), scores.numel() // n, n, float(scale), _code(out_dtype),
+                                             _stream()))
+    return out
+
+
+# ------------------------------------------------------------------ elementwise
+def geglu(x):
+    """x [..., 2F] (value | gate) -> [..., F]."""
+    _dev(x)
+    assert x.is_contiguous() and x.shape[-1] % 2 == 0
+    Fh = x.shape[-1] // 2
+    out = torch.empty(x.shape[:-1] + (Fh,), dtype=x.dtype, device=x.device)
+    _lib.check(_lib.lib().sdamd_geglu(_p(x), _p(out), x.numel() // (2 * Fh), Fh, _code(x.dtype), _stream()))
+    return out
+
+
+def clip_embed(ids, table, pos):
+    _dev(ids, table, pos)
+    assert ids.dtype == torch.int64 and ids.is_contiguous() and table.dtype == pos.dtype
+    B, S = ids.shape
+    D = table.shape[1]
+    assert pos.shape == (S, D)
+    out = torch.empty((B, S, D), dtype=table.dtype, device=table.device)
+    _lib.check(_lib.lib().sdamd_clip_embed(_p(ids), _p(table), _p(pos), _p(out), B * S, S, D, table.shape[0],
+                                           _code(table.dtype), _stream()))
+    return out
+
+
+def concat_channels(a, b):
+    _dev(a, b)
+    assert a.is_contiguous() and b.is_contiguous() and a.dtype == b.dtype and a.shape[:-1] == b.shape[:-1]
+    C1, C2 = a.shape[-1], b.shape[-1]
+    out = torch.empty(a.shape[:-1] + (C1 + C2,), dtype=a.dtype, device=a.device)
+    _lib.check(_lib.lib().sdamd_concat_nhwc(_p(a), _p(b), _p(out), a.numel() // C1, C1, C2, _code(a.dtype), _stream()))
+    return out
+
+
+def add(a, b):
+    _dev(a, b)
+    assert a.shape == b.shape and a.dtype == b.dtype and a.is_contiguous() and b.is_contiguous()
+    out = torch.empty_like(a)
+    _lib.check(_lib.lib().sdamd_add(_p(a), _p(b), _p(out), a.numel(), _code(a.dtype), _stream()))
+    return out
+
+
+def nchw_to_nhwc(x, dtype):
+    """[B,C,H,W] f32 -> [B,H,W,C] dtype."""
+    _dev(x)
+    x = x.contiguous()
+    assert x.dtype == torch.float32 and x.dim() == 4
+    B, C, H, W = x.shape
+    out = torch.empty((B, H, W, C), dtype=dtype, device=x.device)
+    _lib.check(_lib.lib().sdamd_nchw_to_nhwc(_p(x), _p(out), B, C, H * W, _code(dtype), _stream()))
+    return out
+
+
+def nhwc_to_nchw(x):
+    """[B,H,W,C] dtype -> [B,C,H,W] f32."""
+    _dev(x)
+    assert x.is_contiguous() and x.dim() == 4
+    B, H, W, C = x.shape
+    out = torch.empty((B, C, H, W), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().sdamd_nhwc_to_nchw(_p(x), _p(out), B, C, H * W, _code(x.dtype), _stream()))
+    return out
+
+
+def cast(x, dtype):
+    _dev(x)
+    x = x.contiguous()
+    if x.dtype == dtype:
+        return x
+    out = torch.empty(x.shape, dtype=dtype, device=x.device)
+    _lib.check(_lib.lib().sdamd_cast(_p(x), _p(out), x.numel(), _code(x.dtype), _code(dtype), _stream()))
+    return out
+
+
+def silu(x):
+    _dev(x)
+    assert x.dtype == torch.float32 and x.is_contiguous()
+    out = torch.empty_like(x)
+    _lib.check(_lib.lib().sdamd_silu(_p(x), _p(out), x.numel(), _stream()))
+    return out
+
+
+def transpose_last2(x, cols=None):
+    """x [batch, rows, ld] (first ``cols`` columns used) -> [batch, cols, rows]."""
+    _dev(x)
+    assert x.dim() == 3 and x.stride(2) == 1
+    batch, rows, width = x.shape
+    cols = width if cols is None else cols
+    out = torch.empty((batch, cols, rows), dtype=x.dtype, device=x.device)
+    _lib.check(_lib.lib().sdamd_transpose(_p(x), _p(out), batch, rows, cols, x.stride(1), x.stride(0), cols * rows,
+                                          _code(x.dtype), _stream()))
+    return out
+
+
+def image_to_uint8(x):
+    """[B,3,H,W] f32 in (-1,1) -> [B,H,W,3] uint8 (truncating, pipeline.py:158-160)."""
+    _dev(x)
+    assert x.dtype == torch.float32 and x.is_contiguous() and x.shape[1] == 3
+    B, _, H, W = x.shape
+    out = torch.empty((B, H, W, 3), dtype=torch.uint8, device=x.device)
+    _lib.check(_lib.lib().sdamd_image_to_uint8(_p(x), _p(out), B, H * W, _stream()))
+    return out
+
+
+def uint8_to_image(x):
+    """[B,H,W,3] uint8 -> [B,3,H,W] f32 in (-1,1) (pipeline.py:99-104)."""
+    _dev(x)
+    assert x.dtype == torch.uint8 and x.is_contiguous() and x.shape[-1] == 3
+    B, H, W, _ = x.shape
+    out = torch.empty((B, 3, H, W), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().sdamd_uint8_to_image(_p(x), _p(out), B, H * W, _stream()))
+    return out
+
+
+def vae_post_quant(lat, w, b):
+    _dev(lat, w, b)
+    assert lat.dtype == torch.float32 and lat.is_contiguous() and lat.shape[1] == 4 and w.numel() == 16 and b.numel() == 4
+    out = torch.empty_like(lat)
+    _lib.check(_lib.lib().sdamd_vae_post_quant(_p(lat), _p(out), _p(w), _p(b), lat.shape[0], lat.shape[2] * lat.shape[3],
+                                               _stream()))
+    return out
+
+
+def vae_sample(moments, noise, w, b):
+    _dev(moments, noise, w, b)
+    assert moments.dtype == torch.float32 and moments.is_contiguous() and moments.shape[1] == 8
+    noise = noise.contiguous()
+    B, _, H, W = moments.shape
+    assert noise.shape == (B, 4, H, W) and noise.dtype == torch.float32 and w.numel() == 64 and b.numel() == 8
+    out = torch.empty_like(noise)
+    _lib.check(_lib.lib().sdamd_vae_sample(_p(moments), _p(noise), _p(out), _p(w), _p(b), B, H * W, _stream()))
+    return out
+
+
+# ------------------------------------------------------------------ MFMA GEMM / conv / attention
+def gemm(a, w, bias=None, residual=None, act=ACT_NONE, out_f32=False):
+    """a [..., K] (last dim contiguous, uniform row stride), w [N, K] -> [..., N]."""
+    _dev(a, w, bias, residual)
+    K = a.shape[-1]
+    N = w.shape[0]
+    assert w.shape[1] == K and w.is_contiguous() and w.dtype == a.dtype, (a.shape, w.shape, a.dtype, w.dtype)
+    assert a.stride(-1) == 1
+    lead = a.shape[:-1]
+    M = 1
+    for s in lead:
+        M *= s
+    if a.dim() == 2:
+        lda = a.stride(0) if M > 1 else K
+    else:
+        assert a.is_contiguous(), "gemm: batched inputs must be contiguous"
+        lda = K
+    out_dtype = torch.float32 if out_f32 else a.dtype
+    out = torch.empty(lead + (N,), dtype=out_dtype, device=a.device)
+    ldr = 0
+    if residual is not None:
+        assert residual.dtype == a.dtype and residual.is_contiguous() and residual.numel() == M * N
+        ldr = N
+    if bias is not None:
+        assert bias.dtype == torch.float32 and bias.numel() == N and bias.is_contiguous()
+    _lib.check(_lib.lib().sdamd_gemm(_p(a), _p(w), _p(out), _p(bias), _p(residual), M, N, K, lda, K, N, ldr, 1, 0, 0, 0, 0,
+                                     int(act), _code(a.dtype), int(out_f32), _stream()))
+    return out
+
+
+def bmm_nt(a, b, out_f32=False):
+    """Batched a [Bt, M, K] @ b[Bt, N, K]^T -> [Bt, M, N] (both K-contiguous; a may be a strided row view)."""
+    _dev(a, b)
+    assert a.dim() == 3 and b.dim() == 3 and a.dtype == b.dtype and a.stride(2) == 1 and b.stride(2) == 1
+    Bt, M, K = a.shape
+    N = b.shape[1]
+    assert b.shape[0] == Bt and b.shape[2] == K
+    out = torch.empty((Bt, M, N), dtype=torch.float32 if out_f32 else a.dtype, device=a.device)
+    _lib.check(_lib.lib().sdamd_gemm(_p(a), _p(b), _p(out), 0, 0, M, N, K, a.stride(1), b.stride(1), N, 0, Bt, a.stride(0),
+                                     b.stride(0), M * N, 0, ACT_NONE, _code(a.dtype), int(out_f32), _stream()))
+    return out
+
+
+def conv3x3(x, w, bias, residual=None, stride=1, pad_mode=0, upsample=False, act=ACT_NONE, out_f32=False):
+    """x [B,H,W,Cin] NHWC, w [Cout, 9*Cin] ([Cout][ky][kx][Cin]) -> [B,Ho,Wo,Cout]."""
+    _dev(x, w, bias, residual)
+    assert x.is_contiguous() and x.dim() == 4 and w.is_contiguous() and w.dtype == x.dtype
+    B, H, W, Cin = x.shape
+    Cout = w.shape[0]
+    assert w.shape[1] == 9 * Cin, (w.shape, Cin)
+    Hin, Win = (H * 2, W * 2) if upsample else (H, W)
+    if pad_mode == 0:
+        Ho, Wo = (Hin + 2 - 3) // stride + 1, (Win + 2 - 3) // stride + 1
+    else:
+        Ho, Wo = (Hin + 1 - 3) // stride + 1, (Win + 1 - 3) // stride + 1
+    out = torch.empty((B, Ho, Wo, Cout), dtype=torch.float32 if out_f32 else x.dtype, device=x.device)
+    if residual is not None:
+        assert residual.shape == out.shape and residual.dtype == x.dtype and residual.is_contiguous()
+    if bias is not None:
+        assert bias.dtype == torch.float32 and bias.numel() == Cout
+    _lib.check(_lib.lib().sdamd_conv3x3(_p(x), _p(w), _p(out), _p(bias), _p(residual), B, H, W, Cin, Cout, stride, pad_mode,
+                                        int(upsample), int(act), _code(x.dtype), int(out_f32), _stream()))
+    return out
+
+
+def conv3x3_cin_small(x_nchw, w, bias, dtype):
+    """x [B,Cin(3|4),H,W] f32 NCHW, w [3,3,Cin,Cout] f32 -> [B,H,W,Cout] dtype."""
+    _dev(x_nchw, w, bias)
+    x_nchw = x_nchw.contiguous()
+    assert x_nchw.dtype == torch.float32 and w.dtype == torch.float32 and bias.dtype == torch.float32
+    B, Cin, H, W = x_nchw.shape
+    assert w.shape[:3] == (3, 3, Cin) and w.is_contiguous()
+    Cout = w.shape[3]
+    out = torch.empty((B, H, W, Cout), dtype=dtype, device=x_nchw.device)
+    _lib.check(_lib.lib().sdamd_conv3x3_cin_small(_p(x_nchw), _p(w), _p(bias), _p(out), B, H, W, Cin, Cout, _code(dtype),
+                                                  _stream()))
+    return out
+
+
+def conv3x3_cout_small(x, w_packed, bias, cout):
+    """x [B,H,W,Cin] NHWC dtype, w_packed [9, Cin/V, Cout, V] dtype -> [B,Cout,H,W] f32 NCHW."""
+    _dev(x, w_packed, bias)
+    assert x.is_contiguous() and x.dim() == 4 and w_packed.dtype == x.dtype and w_packed.is_contiguous()
+    B, H, W, Cin = x.shape
+    assert w_packed.numel() == 9 * Cin * cout and bias.numel() == cout and bias.dtype == torch.float32
+    out = torch.empty((B, cout, H, W), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().sdamd_conv3x3_cout_small(_p(x), _p(w_packed), _p(bias), _p(out), B, H, W, Cin, cout,
+                                                   _code(x.dtype), _stream()))
+    return out
+
+
+def attention(q, k, v, n_heads, causal=False):
+    """q [B,Sq,C] and k, v [B,Skv,C] views (last dim contiguous; may be column slices of a fused
+    projection) -> [B,Sq,C].  Head h = columns [h*d, (h+1)*d), d = C / n_heads."""
+    _dev(q, k, v)
+    B, Sq, C = q.shape
+    Skv = k.shape[1]
+    d = C // n_heads
+    assert k.shape == (B, Skv, C) and v.shape == (B, Skv, C) and q.dtype == k.dtype == v.dtype
+    assert q.stride(2) == 1 and k.stride(2) == 1 and v.stride(2) == 1
+    out = torch.empty((B, Sq, C), dtype=q.dtype, device=q.device)
+    _lib.check(_lib.lib().sdamd_attention(_p(q), _p(k), _p(v), _p(out), B, n_heads, Sq, Skv, d,
+                                          q.stride(0), q.stride(1), k.stride(0), k.stride(1), v.stride(0), v.stride(1),
+                                          out.stride(0), out.stride(1), int(causal), _code(q.dtype), _stream()))
+    return out
+
+
+def attention_unfused(q, k, v):
+    """Single-head attention with a large head dim (VAE, d=512; decoder.py:43): QK^T and PV as
+    MFMA GEMMs around a row-softmax kernel.  q,k,v [B,S,C] column views of the fused projection."""
+    B, S, C = q.shape
+    scores = bmm_nt(q, k, out_f32=True)                       # [B,S,S] f32
+    probs = softmax_rows(scores, 1.0 / math.sqrt(C), q.dtype)  # [B,S,S]
+    vt = transpose_last2(v)                                    # [B,C,S]
+    return bmm_nt(probs, vt)                                   # [B,S,C]

@@ -1,0 +1,243 @@
+"""``generate()`` with the reference's signature (pipeline.py:15-171) on the HIP path.
+
+Differences a caller can observe (all documented in DESIGN.md):
+  * only the final latents are decoded (the reference decodes and displays a preview every step,
+    pipeline.py:156-164; the returned image is identical);
+  * noise always comes from a CPU ``torch.Generator`` (mt19937) seeded with ``seed`` -- the stream
+    the CPU reference consumes -- drawn up front and uploaded, so the whole step loop is one
+    replayed hipGraph with no host work in it;
+  * ``fp16_enabled=True`` selects the bf16 kernels (the reference's fp16 autocast has no MI355X
+    counterpart here); ``idle_device`` is accepted and ignored (288 GB of HBM: nothing to offload);
+  * extensions: ``prompt`` may be a list (batch of independent images, image i uses ``seed + i``),
+    ``strength_semantics`` selects the img2img schedule slice, ``return_latents`` for tests.
+"""
+import numpy as np
+import torch
+
+from . import engine, ops
+from .sampler.ddpm import DDPMSampler
+
+WIDTH = 512
+HEIGHT = 512
+LATENTS_WIDTH = WIDTH // 8
+LATENT_HEIGHT = HEIGHT // 8
+
+
+def rescale(x, old_range, new_range, clamp=False):
+    """pipeline.py:173-183 (host helper, in place like the reference)."""
+    old_min, old_max = old_range
+    new_min, new_max = new_range
+    x -= old_min
+    x *= (new_max - new_min) / (old_max - old_min)
+    x += new_min
+    if clamp:
+        x = torch.clamp(x, new_min, new_max)
+    return x
+
+
+def get_time_embedding(timestep):
+    """pipeline.py:186-190, same torch-CPU ops -> bit-exact table."""
+    freqs = torch.pow(10000, -torch.arange(start=0, end=160, dtype=torch.float32) / 160)
+    x = torch.tensor([timestep], dtype=torch.float32)[:, None] * freqs[None]
+    return torch.cat([torch.cos(x), torch.sin(x)], dim=-1)
+
+
+class DenoiseLoop:
+    """The hot loop of generate(): 1 hipGraph = [time-bias row gather -> UNet forward on 2B latents
+    -> fused CFG + DDPM step -> step counter++], replayed once per timestep.
+
+    Everything that does not depend on the latents is hoisted out of the loop: prompt K|V
+    projections, the time-embedding MLP and all 22 time projections for every step, the DDPM
+    coefficient table and the pre-drawn noise.
+    """
+
+    def __init__(self, diffusion, context, timesteps, coef, noise, latents, cfg_scale, do_cfg=True, use_graph=True):
+        dev = latents.device
+        self.diffusion = diffusion
+        self.B = latents.shape[0]
+        self.do_cfg = do_cfg
+        self.cfg_scale = float(cfg_scale)
+        self.n_steps = len(timesteps)
+        self.latents = latents.float().contiguous().clone()
+        self.model_in = torch.empty(((2 if do_cfg else 1) * self.B,) + tuple(latents.shape[1:]), dtype=torch.float32, device=dev)
+        self.coef = coef.to(dev).contiguous()
+        self.noise = None if noise is None else noise.to(dev).contiguous()
+        self.counter = torch.zeros(1, dtype=torch.int32, device=dev)
+        unet = diffusion.unet
+        self.kv = unet.prompt_state(context)
+        temb = torch.cat([get_time_embedding(t) for t in timesteps]).to(dev)          # [S,320], bit-exact table
+        self.tb_table = unet.time_bias_table(diffusion.time_embedding(temb))          # [S, sum(Cout)] f32
+        self.tb_row = torch.empty(self.tb_table.shape[1], dtype=torch.float32, device=dev)
+        self.tb = unet.time_bias_slices(self.tb_row)
+        self.graph = None
+        if use_graph:
+            self._capture()
+
+    def _body(self):
+        ops.gather_row(self.tb_row, self.tb_table, step_ptr=self.counter)
+        B = self.B
+        self.model_in[:B].copy_(self.latents)
+        if self.do_cfg:
+            self.model_in[B:].copy_(self.latents)
+        eps = self.diffusion.run(self.model_in, self.kv, self.tb)
+        ops.cfg_ddpm_step(self.latents, eps, self.noise, self.coef, 0, self.cfg_scale, self.do_cfg, step_ptr=self.counter)
+        ops.counter_add(self.counter, 1)
+
+    def _capture(self):
+        keep = self.latents.clone()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):     # warm-up: packs weights, sizes workspaces
+            self._body()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.latents.copy_(keep)
+        self.counter.zero_()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self._body()
+        self.latents.copy_(keep)
+        self.counter.zero_()
+
+    def reset(self, latents):
+        self.latents.copy_(latents)
+        self.counter.zero_()
+
+    def step(self):
+        if self.graph is not None:
+            self.graph.replay()
+        else:
+            self._body()
+
+    def run(self, trace=None):
+        for _ in range(self.n_steps):
+            self.step()
+            if trace is not None:
+                trace.append(self.latents.clone())
+        return self.latents
+
+
+def _resolve_sampler(name):
+    upper, capital = f"{name.upper()}Sampler", f"{name.capitalize()}Sampler"
+    if upper in globals():
+        return globals()[upper]
+    if capital in globals():
+        return globals()[capital]
+    raise ValueError(f"Sampler '{name}' not found")
+
+
+def _token_tensor(tokenizer, prompts, device):
+    ids = tokenizer.batch_encode_plus(list(prompts), padding="max_length", max_length=77).input_ids
+    return torch.tensor(ids, dtype=torch.long, device=device)
+
+
+def encode_prompts(clip, pos_tokens, neg_tokens=None):
+    """[pos_0..pos_B-1, neg_0..neg_B-1] context (pipeline.py:64 generalised to a batch)."""
+    toks = pos_tokens if neg_tokens is None else torch.cat([pos_tokens, neg_tokens])
+    return clip(toks)
+
+
+def decode_to_uint8(decoder, latents, micro_batch=8):
+    """Final VAE decode + rescale/clamp/truncate -> uint8 [B,H,W,3] on the device."""
+    outs = []
+    for i in range(0, latents.shape[0], micro_batch):
+        outs.append(ops.image_to_uint8(decoder(latents[i:i + micro_batch].contiguous())))
+    return outs[0] if len(outs) == 1 else torch.cat(outs)
+
+
+def prepare_latents(seeds, sampler_cls, steps, shape, device, encoder=None, images_u8=None, strength=0.7,
+                    strength_semantics="reference"):
+    """Per image: its own CPU generator and the reference's RNG call order:
+    txt2img: randn(latents) then one randn per step with t>0; img2img: randn(encoder noise),
+    randn(add_noise), then the per-step draws.  Returns (timesteps, coef, noise [S,B,...], latents)."""
+    samplers = []
+    for s in seeds:
+        g = torch.Generator(device="cpu")
+        if s is not None:
+            g.manual_seed(int(s))
+        sm = sampler_cls(g)
+        sm.set_steps(steps)
+        samplers.append(sm)
+    if images_u8 is not None:
+        enc_noise = torch.stack([sm.draw_noise(shape[1:]) for sm in samplers]).to(device)
+        latents = encoder(ops.uint8_to_image(images_u8), enc_noise)
+        for sm in samplers:
+            (sm.set_strength if strength_semantics == "reference" else sm.set_strength_steps)(strength=strength)
+        if len(samplers[0].timesteps) == 0:
+            raise IndexError(
+                f"strength={strength} leaves no timesteps with the reference's set_strength semantics "
+                f"(sampler/ddpm.py:50-53 slices {steps} steps at {samplers[0].start_step}); "
+                "pass strength_semantics='intended'")
+        t0 = samplers[0].timesteps[0]
+        latents = torch.cat([sm.add_noise(latents[i:i + 1], t0) for i, sm in enumerate(samplers)])
+    else:
+        latents = torch.stack([sm.draw_noise(shape[1:]) for sm in samplers]).to(device)
+    timesteps = samplers[0].timesteps
+    coef = samplers[0].coefficient_table(timesteps)
+    noise = torch.zeros((len(timesteps), len(seeds)) + tuple(shape[1:]), dtype=torch.float32)
+    for si, t in enumerate(timesteps):
+        if int(t) > 0:
+            for bi, sm in enumerate(samplers):
+                noise[si, bi] = sm.draw_noise(shape[1:])
+    return timesteps, coef, noise, latents
+
+
+def generate(
+    prompt,
+    negative_prompt,
+    input_image=None,
+    strength=0.7,
+    do_cfg=True,
+    cfg_scale=7,
+    sampler="ddpm",
+    steps=20,
+    models=(),
+    seed=None,
+    device=None,
+    idle_device=None,
+    tokenizer=None,
+    fp16_enabled=False,
+    *,
+    strength_semantics="reference",
+    compute_dtype=None,
+    use_graph=True,
+    return_latents=False,
+    trace=None,
+):
+    with torch.no_grad():
+        if not (0 < strength <= 1):
+            raise ValueError("Strength must be between 0 and 1")
+        device = torch.device(device if device is not None else "cuda")
+        if device.type != "cuda":
+            raise ops._lib.SdamdError("sd_amd.pipeline.generate runs on the HIP device only (device='cuda'); no CPU fallback")
+        batched = isinstance(prompt, (list, tuple))
+        prompts = list(prompt) if batched else [prompt]
+        B = len(prompts)
+        negs = list(negative_prompt) if isinstance(negative_prompt, (list, tuple)) else [negative_prompt] * B
+        dtype = compute_dtype or (torch.bfloat16 if fp16_enabled else torch.float32)
+        for m in models.values():
+            m.to(device)
+            engine.set_compute_dtype(m, dtype)
+
+        pos = _token_tensor(tokenizer, prompts, device)
+        context = encode_prompts(models["clip"], pos, _token_tensor(tokenizer, negs, device) if do_cfg else None)
+
+        sampler_cls = _resolve_sampler(sampler)
+        seeds = [None if seed is None else seed + i for i in range(B)]
+        shape = (1, 4, LATENT_HEIGHT, LATENTS_WIDTH)
+        images_u8 = None
+        if input_image is not None:
+            imgs = list(input_image) if isinstance(input_image, (list, tuple)) else [input_image] * B
+            arr = np.stack([np.array(im.resize((WIDTH, HEIGHT))) for im in imgs])
+            images_u8 = torch.from_numpy(arr).to(device).contiguous()
+        timesteps, coef, noise, latents = prepare_latents(
+            seeds, sampler_cls, steps, shape, device, models.get("encoder") if input_image is not None else None,
+            images_u8, strength, strength_semantics)
+
+        loop = DenoiseLoop(models["diffusion"], context, timesteps, coef, noise, latents, cfg_scale, do_cfg, use_graph)
+        final = loop.run(trace)
+        images = decode_to_uint8(models["decoder"], final)
+        out = images.cpu().numpy()
+        if return_latents:
+            return (out if batched else out[0]), final
+        return out if batched else out[0]

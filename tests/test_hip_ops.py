@@ -1,0 +1,308 @@
+"""GPU parity of every libsdamd kernel (through the C-ABI, via sd_amd.ops) against the CPU oracle.
+
+Tolerances: f32 kernels <= 2e-6 relative L2 per op (exact-f32 MFMA = fmaf chain, different summation
+order than the CPU), bf16 kernels <= 1e-2 per op (inputs/outputs rounded to bf16, f32 accumulate);
+the sampler step kernel is bit-exact.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import sd_amd
+from sd_amd import ops, synth
+from sd_amd.sampler.ddpm import DDPMSampler
+from oracle import sd_oracle as O
+from conftest import rel_l2, hin
+
+pytestmark = pytest.mark.gpu
+torch.set_grad_enabled(False)
+DEV = "cuda"
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+def tol(dtype, f32=2e-6, bf16=1e-2):
+    return f32 if dtype == torch.float32 else bf16
+
+
+def rnd(name, shape, scale=1.0):
+    return hin("ops." + name, shape, scale)
+
+
+def q(x, dtype):
+    """Round a CPU f32 tensor through the compute dtype (what the kernel sees)."""
+    return x.to(dtype).float()
+
+
+def to_nhwc(x, dtype):
+    return x.permute(0, 2, 3, 1).contiguous().to(dtype).to(DEV)
+
+
+def from_nhwc(y):
+    return y.float().cpu().permute(0, 3, 1, 2)
+
+
+# ------------------------------------------------------------------ sampler kernels
+@pytest.mark.parametrize("B", [1, 3])
+def test_cfg_ddpm_step_bit_exact(B):
+    n = 4 * 16 * 16
+    samp = DDPMSampler(torch.Generator().manual_seed(0))
+    samp.set_steps(50)
+    coef = samp.coefficient_table()
+    lat = rnd("step.lat", (B, 4, 16, 16), 2.0)
+    eps = rnd("step.eps", (2 * B, 4, 16, 16), 1.5)
+    noise = rnd("step.noise", (50, B, 4, 16, 16))
+    orc = O.DDPMSampler(torch.Generator().manual_seed(0))
+    orc.set_steps(50)
+    for si in (0, 17, 48, 49):
+        t = int(samp.timesteps[si])
+        sa, sb, c0, cx, sigma = orc.coefficients(t)
+        e = 7.5 * (eps[:B] - eps[B:]) + eps[B:]
+        want = ((lat - sb * e) / sa) * c0 + cx * lat
+        if t > 0:
+            want = want + sigma * noise[si]
+        got = ops.cfg_ddpm_step(lat.to(DEV).clone(), eps.to(DEV), noise.to(DEV), coef.to(DEV), si, 7.5).cpu()
+        assert torch.equal(got, want), (si, (got - want).abs().max())
+        ctr = torch.tensor([si], dtype=torch.int32, device=DEV)
+        got2 = ops.cfg_ddpm_step(lat.to(DEV).clone(), eps.to(DEV), noise.to(DEV), coef.to(DEV), 0, 7.5, step_ptr=ctr).cpu()
+        assert torch.equal(got2, want)
+        ops.counter_add(ctr, 1)
+        assert int(ctr.cpu()) == si + 1
+
+
+def test_sampler_step_and_add_noise_match_golden():
+    from conftest import golden
+    g = golden("ddpm_step")
+    for steps, ts in ((50, (980, 500, 20, 0)), (20, (950, 0))):
+        for t in ts:
+            sm = DDPMSampler(torch.Generator().manual_seed(1234 + t))
+            sm.set_steps(steps)
+            out = sm.step(torch.tensor(t), hin(f"ddpm.lat.{t}", (1, 4, 16, 16), 2.0).to(DEV),
+                          hin(f"ddpm.eps.{t}", (4, 16, 16), 1.5).to(DEV))
+            assert np.array_equal(out.cpu().numpy(), g[f"step{steps}_{t}"]), (steps, t)
+    sm = DDPMSampler(torch.Generator().manual_seed(77))
+    sm.set_steps(50)
+    out = sm.add_noise(hin("ddpm.an", (1, 4, 16, 16)).to(DEV), torch.tensor(780))
+    assert np.array_equal(out.cpu().numpy(), g["add_noise_780"])
+
+
+def test_gather_row_and_silu():
+    table = rnd("gather", (5, 96))
+    dst = torch.empty(96, device=DEV)
+    ops.gather_row(dst, table.to(DEV), 3)
+    assert torch.equal(dst.cpu(), table[3])
+    ctr = torch.tensor([4], dtype=torch.int32, device=DEV)
+    ops.gather_row(dst, table.to(DEV), step_ptr=ctr)
+    assert torch.equal(dst.cpu(), table[4])
+    x = rnd("silu", (1, 1280), 4.0)
+    assert rel_l2(ops.silu(x.to(DEV)).cpu(), F.silu(x)) < 1e-6
+
+
+# ------------------------------------------------------------------ norms
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,C,H,W,eps,silu", [
+    (2, 320, 16, 16, 1e-5, True), (2, 320, 8, 8, 1e-6, False), (1, 2560, 8, 8, 1e-5, True),
+    (2, 1920, 4, 4, 1e-5, True), (1, 960, 16, 16, 1e-5, True), (1, 128, 32, 32, 1e-5, True),
+    (3, 64, 2, 2, 1e-5, False), (1, 512, 64, 64, 1e-5, True), (1, 1280, 1, 1, 1e-5, True)])
+def test_groupnorm(dtype, B, C, H, W, eps, silu):
+    x = q(rnd(f"gn.{C}.{H}", (B, C, H, W), 2.0) + 0.5, dtype)
+    gamma, beta = rnd(f"gn.g.{C}", (C,), 0.2) + 1.0, rnd(f"gn.b.{C}", (C,), 0.2)
+    want = F.group_norm(x, 32, gamma, beta, eps)
+    if silu:
+        want = F.silu(want)
+    got = from_nhwc(ops.groupnorm(to_nhwc(x, dtype), gamma.to(DEV), beta.to(DEV), eps, silu))
+    assert rel_l2(got, want) < tol(dtype, 2e-6, 6e-3)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("rows,C", [(128, 320), (77, 768), (5, 1280), (64, 640)])
+def test_layernorm(dtype, rows, C):
+    x = q(rnd(f"ln.{C}", (rows, C), 2.0) + 0.3, dtype)
+    gamma, beta = rnd(f"ln.g.{C}", (C,), 0.2) + 1.0, rnd(f"ln.b.{C}", (C,), 0.2)
+    want = F.layer_norm(x, (C,), gamma, beta, 1e-5)
+    got = ops.layernorm(x.to(dtype).to(DEV), gamma.to(DEV), beta.to(DEV)).float().cpu()
+    assert rel_l2(got, want) < tol(dtype, 2e-6, 6e-3)
+
+
+# ------------------------------------------------------------------ elementwise
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_geglu_concat_add_cast(dtype):
+    x = q(rnd("geglu", (3, 50, 2 * 1280), 3.0), dtype)
+    val, gate = x.chunk(2, dim=-1)
+    assert rel_l2(ops.geglu(x.to(dtype).to(DEV)).float().cpu(), val * F.gelu(gate)) < tol(dtype, 1e-6, 5e-3)
+    a, b = q(rnd("cat.a", (2, 4, 4, 1280)), dtype), q(rnd("cat.b", (2, 4, 4, 640)), dtype)
+    got = ops.concat_channels(a.to(dtype).to(DEV), b.to(dtype).to(DEV)).float().cpu()
+    assert torch.equal(got, torch.cat([a, b], -1))
+    c = q(rnd("add.c", (2, 4, 4, 1280)), dtype)
+    assert rel_l2(ops.add(a.to(dtype).to(DEV), c.to(dtype).to(DEV)).float().cpu(), a + c) < tol(dtype, 1e-7, 5e-3)
+    y = rnd("cast", (7, 33))
+    assert torch.equal(ops.cast(y.to(DEV), dtype).float().cpu(), y.to(dtype).float())
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_layout_roundtrip_and_embed(dtype):
+    x = q(rnd("layout", (2, 40, 7, 9)), dtype)
+    nhwc = ops.nchw_to_nhwc(x.to(DEV), dtype)
+    assert torch.equal(nhwc.float().cpu(), x.permute(0, 2, 3, 1))
+    assert torch.equal(ops.nhwc_to_nchw(nhwc).cpu(), x)
+    t = rnd("tr", (2, 70, 96)).to(dtype)
+    assert torch.equal(ops.transpose_last2(t.to(DEV), 40).cpu(),
+                       t[:, :, :40].transpose(1, 2).contiguous())
+    table, pos = rnd("emb.t", (1000, 768)).to(dtype), rnd("emb.p", (77, 768)).to(dtype)
+    ids = torch.randint(0, 1000, (2, 77), generator=torch.Generator().manual_seed(1))
+    got = ops.clip_embed(ids.to(DEV), table.to(DEV), pos.to(DEV)).float().cpu()
+    assert rel_l2(got, table.float()[ids] + pos.float()) < tol(dtype, 1e-7, 4e-3)
+
+
+def test_image_quantisation_and_vae_scalar_kernels():
+    x = rnd("img", (2, 3, 16, 24), 1.3)
+    want = O.rescale(x, (-1, 1), (0, 255), clamp=True).permute(0, 2, 3, 1).to(torch.uint8)
+    assert torch.equal(ops.image_to_uint8(x.to(DEV)).cpu(), want)
+    u8 = torch.randint(0, 256, (2, 16, 24, 3), dtype=torch.uint8, generator=torch.Generator().manual_seed(2))
+    want = O.rescale(u8.float(), (0, 255), (-1, 1)).permute(0, 3, 1, 2)
+    assert torch.equal(ops.uint8_to_image(u8.to(DEV)).cpu(), want)
+    lat, w, b = rnd("pq.x", (2, 4, 8, 8)), rnd("pq.w", (4, 4, 1, 1)), rnd("pq.b", (4,))
+    assert rel_l2(ops.vae_post_quant(lat.to(DEV), w.to(DEV), b.to(DEV)).cpu(), F.conv2d(lat / 0.18215, w, b)) < 1e-6
+    m, nz, w8, b8 = rnd("vs.x", (2, 8, 8, 8), 3.0), rnd("vs.n", (2, 4, 8, 8)), rnd("vs.w", (8, 8, 1, 1)), rnd("vs.b", (8,))
+    mean, logvar = F.conv2d(m, w8, b8).chunk(2, dim=1)
+    want = (mean + logvar.clamp(-30, 20).exp().sqrt() * nz) * 0.18215
+    assert rel_l2(ops.vae_sample(m.to(DEV), nz.to(DEV), w8.to(DEV), b8.to(DEV)).cpu(), want) < 1e-6
+
+
+def test_softmax_rows():
+    s = rnd("sm", (3, 50, 4096), 30.0)
+    want = F.softmax(s * 0.0442, dim=-1)
+    assert rel_l2(ops.softmax_rows(s.to(DEV), 0.0442, torch.float32).cpu(), want) < 2e-6
+
+
+# ------------------------------------------------------------------ MFMA GEMM
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K,bias,res,act", [
+    (300, 320, 320, True, True, 0), (77, 3072, 768, True, False, 1), (1, 1280, 320, True, False, 2),
+    (8192, 320, 1280, True, True, 0), (130, 2560, 320, True, False, 0), (64, 1280, 5120, False, False, 0),
+    (4096, 960, 320, False, False, 0), (154, 640, 768, False, False, 0), (1000, 128, 256, True, True, 0)])
+def test_gemm(dtype, M, N, K, bias, res, act):
+    a = q(rnd(f"gemm.a.{M}.{K}", (M, K)), dtype)
+    w = q(rnd(f"gemm.w.{N}.{K}", (N, K), 1.0 / math.sqrt(K)), dtype)
+    b = rnd(f"gemm.b.{N}", (N,)) if bias else None
+    r = q(rnd(f"gemm.r.{M}.{N}", (M, N)), dtype) if res else None
+    want = (a.double() @ w.double().t())
+    if bias:
+        want = want + b.double()
+    if res:
+        want = want + r.double()
+    want = want.float()
+    if act == 1:
+        want = want * torch.sigmoid(1.702 * want)
+    elif act == 2:
+        want = F.silu(want)
+    dev = lambda t: None if t is None else t.to(DEV)
+    got = ops.gemm(a.to(dtype).to(DEV), w.to(dtype).to(DEV), dev(b), None if r is None else r.to(dtype).to(DEV), act)
+    assert got.dtype == dtype
+    assert rel_l2(got.float().cpu(), want) < tol(dtype, 2e-6, 4e-3)
+    if dtype == torch.bfloat16:   # f32 output from bf16 operands keeps the accumulator's precision
+        got32 = ops.gemm(a.to(dtype).to(DEV), w.to(dtype).to(DEV), dev(b), None if r is None else r.to(dtype).to(DEV), act, out_f32=True)
+        assert got32.dtype == torch.float32 and rel_l2(got32.cpu(), want) < 2e-5
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_strided_views_and_batched(dtype):
+    qkv = q(rnd("bmm.qkv", (2, 192, 3 * 512)), dtype)
+    d = qkv.to(dtype).to(DEV)
+    qv, kv, vv = d[..., :512], d[..., 512:1024], d[..., 1024:]
+    want = torch.einsum("bmk,bnk->bmn", qkv[..., :512].double(), qkv[..., 512:1024].double()).float()
+    assert rel_l2(ops.bmm_nt(qv, kv, out_f32=True).cpu(), want) < tol(dtype, 2e-6, 2e-5)
+    want_attn = O.attention_core(qkv[..., :512], qkv[..., 512:1024], qkv[..., 1024:], 1)
+    assert rel_l2(ops.attention_unfused(qv, kv, vv).float().cpu(), want_attn) < tol(dtype, 3e-6, 1e-2)
+
+
+# ------------------------------------------------------------------ implicit-GEMM conv
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,Cin,Cout,H,W,stride,pad_mode,ups,res", [
+    (2, 64, 128, 8, 8, 1, 0, False, False), (2, 320, 320, 16, 16, 1, 0, False, True),
+    (1, 320, 320, 16, 16, 2, 0, False, False), (1, 128, 128, 16, 16, 2, 1, False, False),
+    (1, 640, 640, 8, 8, 1, 0, True, False), (2, 1280, 640, 4, 4, 1, 0, False, True),
+    (1, 128, 256, 9, 7, 1, 0, False, False), (1, 256, 256, 15, 15, 2, 1, False, False),
+    (3, 960, 320, 8, 8, 1, 0, False, False)])
+def test_conv3x3(dtype, B, Cin, Cout, H, W, stride, pad_mode, ups, res):
+    x = q(rnd(f"conv.x.{Cin}.{H}", (B, Cin, H, W)), dtype)
+    w = q(rnd(f"conv.w.{Cin}.{Cout}", (Cout, Cin, 3, 3), 1.0 / math.sqrt(9 * Cin)), dtype)
+    b = rnd(f"conv.b.{Cout}", (Cout,))
+    xin = F.interpolate(x, scale_factor=2, mode="nearest") if ups else x
+    if pad_mode == 1:
+        want = F.conv2d(F.pad(xin.double(), (0, 1, 0, 1)), w.double(), b.double(), stride=stride)
+    else:
+        want = F.conv2d(xin.double(), w.double(), b.double(), stride=stride, padding=1)
+    r = None
+    if res:
+        r = q(rnd(f"conv.r.{Cout}.{H}", tuple(want.shape)), dtype)
+        want = want + r
+    wp = w.permute(0, 2, 3, 1).reshape(Cout, -1).contiguous().to(dtype).to(DEV)
+    got = ops.conv3x3(to_nhwc(x, dtype), wp, b.to(DEV), None if r is None else to_nhwc(r, dtype), stride, pad_mode, ups)
+    assert tuple(got.shape) == (B, want.shape[2], want.shape[3], Cout)
+    assert rel_l2(from_nhwc(got), want.float()) < tol(dtype, 2e-6, 4e-3)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_small_channel_convs(dtype):
+    from sd_amd import engine
+    for cin, cout in ((4, 320), (3, 128), (4, 512)):
+        conv = torch.nn.Conv2d(cin, cout, 3, padding=1)
+        synth.load_hashed(conv, f"ops.cin{cin}.")
+        x = rnd(f"cin.x.{cin}", (2, cin, 12, 10))
+        want = conv(x)
+        conv.to(DEV)
+        got = ops.conv3x3_cin_small(x.to(DEV), engine.conv3x3_cin_small_w(conv), engine.f32(conv.bias), dtype)
+        assert rel_l2(from_nhwc(got), want) < tol(dtype, 2e-6, 4e-3)
+    for cin, cout in ((320, 4), (128, 3), (512, 8)):
+        conv = torch.nn.Conv2d(cin, cout, 3, padding=1)
+        synth.load_hashed(conv, f"ops.cout{cout}.")
+        x = q(rnd(f"cout.x.{cin}", (2, cin, 9, 11)), dtype)
+        want = F.conv2d(x, q(conv.weight, dtype), conv.bias, padding=1)
+        conv.to(DEV)
+        got = ops.conv3x3_cout_small(to_nhwc(x, dtype), engine.conv3x3_cout_small_w(conv, dtype), engine.f32(conv.bias), cout)
+        assert rel_l2(got.cpu(), want) < tol(dtype, 3e-6, 1e-5)
+
+
+# ------------------------------------------------------------------ flash attention
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,H,d,Sq,Skv,causal", [
+    (2, 8, 40, 256, 256, False), (1, 8, 40, 1024, 1024, False), (2, 8, 80, 144, 144, False),
+    (2, 8, 160, 64, 64, False), (1, 8, 160, 300, 300, False), (2, 12, 64, 77, 77, True),
+    (2, 8, 40, 256, 77, False), (2, 8, 80, 64, 77, False), (2, 8, 160, 16, 77, False), (1, 8, 40, 100, 33, False)])
+def test_flash_attention(dtype, B, H, d, Sq, Skv, causal):
+    C = H * d
+    qq = q(rnd(f"att.q.{d}.{Sq}", (B, Sq, C), 1.5), dtype)
+    kk = q(rnd(f"att.k.{d}.{Skv}", (B, Skv, C), 1.5), dtype)
+    vv = q(rnd(f"att.v.{d}.{Skv}", (B, Skv, C)), dtype)
+    want = O.attention_core(qq, kk, vv, H, causal)
+    got = ops.attention(qq.to(dtype).to(DEV), kk.to(dtype).to(DEV), vv.to(dtype).to(DEV), H, causal)
+    assert rel_l2(got.float().cpu(), want) < tol(dtype, 3e-6, 1e-2)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_flash_attention_fused_qkv_views_and_spiky_scores(dtype):
+    """Strided q/k/v views of one fused projection; one key dominates each row (forces the online
+    softmax to rescale mid-sweep)."""
+    B, S, H, d = 1, 512, 8, 40
+    C = H * d
+    qkv = rnd("att.fused", (B, S, 3 * C))
+    qkv[:, 300, C:2 * C] *= 12.0          # a late, very large key
+    qkv = q(qkv, dtype)
+    want = O.attention_core(qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:], H)
+    dv = qkv.to(dtype).to(DEV)
+    got = ops.attention(dv[..., :C], dv[..., C:2 * C], dv[..., 2 * C:], H)
+    assert rel_l2(got.float().cpu(), want) < tol(dtype, 3e-6, 1e-2)
+
+
+def test_argument_errors_are_reported():
+    from sd_amd import _lib
+    a = torch.zeros((4, 100), device=DEV)
+    with pytest.raises(_lib.SdamdError, match="multiple"):
+        ops.gemm(a, torch.zeros((16, 100), device=DEV))
+    with pytest.raises(_lib.SdamdError, match="head dim"):
+        ops.attention(torch.zeros((1, 8, 96), device=DEV), torch.zeros((1, 8, 96), device=DEV), torch.zeros((1, 8, 96), device=DEV), 2)
+    with pytest.raises(_lib.SdamdError, match="HIP device"):
+        ops.layernorm(torch.zeros(4, 320), torch.ones(320), torch.zeros(320))
