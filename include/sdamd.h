@@ -96,6 +96,9 @@ int sdamd_gemm(const void* A, const void* W, void* C, const float* bias, const v
                int N, int K, int lda, int ldw, int ldc, int ldr, int batch, long long strideA,
                long long strideW, long long strideC, long long strideR, int act, int dtype,
                int out_f32, void* stream);
+/* block tile the GEMM/conv launcher picks for an M x N problem (BM*1000+BN); host-only helper
+ * used by bench.py to attribute launches to kernel instantiations (no reference counterpart) */
+int sdamd_gemm_tile(int M, int N, int batch);
 /* ---- implicit-GEMM conv3x3 over NHWC: nn.Conv2d(k=3) of diffusion.py:9,13,146,204-221,
  * decoder.py:10-13,92-111, encoder.py:13-45.  w [Cout][ky][kx][Cin]; pad_mode 0 = pad 1,
  * 1 = bottom/right pad only (encoder.py:65-66); upsample=1 fuses F.interpolate(nearest,2x)

@@ -250,32 +250,42 @@ class DDPMSampler:
         return t - self.training_steps // self.steps
 
     def coefficients(self, t):
-        """(c_x0_inv_sqrt_abar, sqrt(1-abar), c0, cx, sigma) as the 0-dim fp32 tensors of :59-77,:35-48."""
+        """(sqrt(abar_t), sqrt(1-abar_t), c0, cx, sigma): the 0-dim fp32 values of :59-77, :35-48.
+
+        Evaluated in numpy float32 scalar arithmetic, op for op as the reference writes them.
+        torch's own scalar ``** 0.5`` / ``sqrt`` is NOT correctly rounded on every host (an AMD
+        EPYC host returned sqrt values 1 ulp off an Intel host's); IEEE float32 arithmetic in
+        numpy is, and reproduces the fixture host's reference values bit for bit."""
+        f = np.float32
         t = int(t)
         pt = self._prev(t)
-        a_t = self.alpha_cumprod[t]
-        a_p = self.alpha_cumprod[pt] if pt >= 0 else self.one
-        b_t, b_p = 1 - a_t, 1 - a_p
+        a_t = f(self.alpha_cumprod[t].item())
+        a_p = f(self.alpha_cumprod[pt].item()) if pt >= 0 else f(1.0)
+        b_t, b_p = f(1) - a_t, f(1) - a_p
         cur_a = a_t / a_p
-        cur_b = 1 - cur_a
-        c0 = (a_p ** 0.5 * cur_b) / b_t
-        cx = cur_a ** 0.5 * b_p / b_t
-        var = torch.clamp((1 - a_p) / (1 - a_t) * (1 - a_t / a_p), min=1e-20)
-        return a_t ** 0.5, b_t ** 0.5, c0, cx, var ** 0.5
+        cur_b = f(1) - cur_a
+        c0 = (np.sqrt(a_p) * cur_b) / b_t
+        cx = np.sqrt(cur_a) * b_p / b_t
+        var = np.maximum((f(1) - a_p) / (f(1) - a_t) * (f(1) - a_t / a_p), f(1e-20))
+        return tuple(torch.tensor(v, dtype=torch.float32) for v in (np.sqrt(a_t), np.sqrt(b_t), c0, cx, np.sqrt(var)))
 
-    def step(self, t, latents, model_output):                                       # :55-87
+    def step(self, t, latents, model_output, noise=None):                           # :55-87
+        """``noise``: supply the N(0,1) draw instead of consuming the generator (torch's CPU randn
+        differs by ulps between host ISAs, so fixtures carry the draw the reference made)."""
         sa, sb, c0, cx, sigma = self.coefficients(t)
         x0 = (latents - sb * model_output) / sa
         prev = x0 * c0 + cx * latents
         if int(t) > 0:
-            noise = torch.randn(model_output.shape, generator=self.generator, dtype=model_output.dtype)
+            if noise is None:
+                noise = torch.randn(model_output.shape, generator=self.generator, dtype=model_output.dtype)
             prev = prev + sigma * noise
         return prev
 
-    def add_noise(self, x, t):                                                      # :91-111
-        a = self.alpha_cumprod[t]
-        noise = torch.randn(x.shape, generator=self.generator, dtype=x.dtype)
-        return (a ** 0.5) * x + ((1 - a) ** 0.5) * noise
+    def add_noise(self, x, t, noise=None):                                          # :91-111
+        a = np.float32(self.alpha_cumprod[int(t)].item())
+        if noise is None:
+            noise = torch.randn(x.shape, generator=self.generator, dtype=x.dtype)
+        return float(np.sqrt(a)) * x + float(np.sqrt(np.float32(1) - a)) * noise
 
 
 def get_time_embedding(t):

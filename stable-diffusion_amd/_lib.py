@@ -37,6 +37,7 @@ SIGNATURES = {
     "sdamd_vae_post_quant": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
     "sdamd_vae_sample": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "sdamd_gemm": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _ll, _ll, _ll, _ll, _i, _i, _i, _vp]),
+    "sdamd_gemm_tile": (_i, [_i, _i, _i]),
     "sdamd_conv3x3": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "sdamd_conv3x3_cin_small": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "sdamd_conv3x3_cout_small": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),

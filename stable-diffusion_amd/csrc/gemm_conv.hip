@@ -349,16 +349,27 @@ static int launch_gemm(GemmArgs& a, int batch, hipStream_t st) {
   return 0;
 }
 
+// Tile choice (pure function of the problem size, also exported for the bench's bookkeeping):
+// prefer 128x128; drop to smaller tiles when the grid would leave most of the 256 CUs idle or
+// when N wastes a large part of a 128-wide tile.  Returns BM*1000 + BN.
+static int choose_tile(int M, int N, int batch) {
+  auto blocks = [&](int bm, int bn) { return (long long)((M + bm - 1) / bm) * ((N + bn - 1) / bn) * batch; };
+  const bool n64 = (N % 128) != 0 && (N % 128) <= 64;  // e.g. N = 320: 5 x 64 exact, 128 wastes 17 %
+  if (!n64 && blocks(128, 128) >= 512) return 128128;
+  if (blocks(128, 64) >= 512) return 128064;
+  if (M > 64 && blocks(128, 64) >= 256) return 128064;
+  return 64064;
+}
+
+extern "C" int sdamd_gemm_tile(int M, int N, int batch) { return choose_tile(M, N, batch); }
+
 template <typename T, bool CONV>
 static int pick_tile(GemmArgs& a, int batch, hipStream_t st) {
-  // Prefer 128x128; drop to smaller tiles when the grid would leave most of the 256 CUs idle
-  // or when N wastes a large part of a 128-wide tile.
-  auto blocks = [&](int bm, int bn) { return (long long)((a.M + bm - 1) / bm) * ((a.N + bn - 1) / bn) * batch; };
-  const bool n64 = (a.N % 128) != 0 && (a.N % 128) <= 64;  // e.g. N = 320: 5 x 64 exact, 128 wastes 17 %
-  if (!n64 && blocks(128, 128) >= 512) return launch_gemm<T, 128, 128, CONV>(a, batch, st);
-  if (blocks(128, 64) >= 512) return launch_gemm<T, 128, 64, CONV>(a, batch, st);
-  if (a.M > 64 && blocks(128, 64) >= 256) return launch_gemm<T, 128, 64, CONV>(a, batch, st);
-  return launch_gemm<T, 64, 64, CONV>(a, batch, st);
+  switch (choose_tile(a.M, a.N, batch)) {
+    case 128128: return launch_gemm<T, 128, 128, CONV>(a, batch, st);
+    case 128064: return launch_gemm<T, 128, 64, CONV>(a, batch, st);
+    default: return launch_gemm<T, 64, 64, CONV>(a, batch, st);
+  }
 }
 
 static int check_common(const GemmArgs& a, int dtype, const char* what) {

@@ -1,0 +1,74 @@
+"""Multi-GPU scaling of generate(): independent image-batch sharding, one collective.
+
+One process per GPU (torch.distributed; backend "nccl" is RCCL over xGMI on ROCm, "gloo" on CPU
+for tests).  Rank r owns images [r*B/N, (r+1)*B/N); every image has its own seed, so an image
+does not depend on N (shard invariance).  The only communication on the path is one all-gather of
+the decoded uint8 images at the end of generate: no tensor/sequence parallelism.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None):
+    """Initialise from torchrun's RANK/WORLD_SIZE/LOCAL_RANK/MASTER_*; returns (rank, world, local)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def shard_range(total, rank, world):
+    """Contiguous slice [lo, hi) of ``total`` images owned by ``rank``; sizes differ by at most 1."""
+    if not (0 <= rank < world):
+        raise ValueError(f"rank {rank} outside world of {world}")
+    base, extra = divmod(total, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def all_gather_images(images, total=None):
+    """images uint8 [b_local, H, W, 3] on every rank -> [total, H, W, 3] in rank order.
+    Equal shard sizes use one all_gather_into_tensor; ragged shards are padded to the largest."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return images
+    world = dist.get_world_size()
+    images = images.contiguous()
+    sizes = [torch.zeros(1, dtype=torch.int64, device=images.device) for _ in range(world)]
+    dist.all_gather(sizes, torch.tensor([images.shape[0]], dtype=torch.int64, device=images.device))
+    sizes = [int(s) for s in sizes]
+    if len(set(sizes)) == 1:
+        out = torch.empty((world * sizes[0],) + tuple(images.shape[1:]), dtype=images.dtype, device=images.device)
+        dist.all_gather_into_tensor(out, images)
+    else:
+        mx = max(sizes)
+        pad = torch.zeros((mx,) + tuple(images.shape[1:]), dtype=images.dtype, device=images.device)
+        pad[:images.shape[0]] = images
+        bufs = [torch.empty_like(pad) for _ in range(world)]
+        dist.all_gather(bufs, pad)
+        out = torch.cat([b[:n] for b, n in zip(bufs, sizes)])
+    if total is not None and out.shape[0] != total:
+        raise RuntimeError(f"gathered {out.shape[0]} images, expected {total}")
+    return out
+
+
+def max_over_ranks(value, device):
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return value
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t)
+
+
+def barrier():
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()

@@ -38,6 +38,49 @@ def _p(t):
     return 0 if t is None else t.data_ptr()
 
 
+class LaunchTimer:
+    """Optional per-launch timing with HIP events recorded on the launch stream (used by
+    bench.py's roofline leg; None in normal operation).  records: (kind, work, start, end) with
+    ``work`` = algorithmic FLOPs (MFMA kernels) or bytes (bandwidth kernels) of that launch."""
+
+    def __init__(self):
+        self.records = []
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for kind, work, s, e in self.records:
+            ent = out.setdefault(kind, {"launches": 0, "ms": 0.0, "work": 0.0})
+            ent["launches"] += 1
+            ent["ms"] += s.elapsed_time(e)
+            ent["work"] += work
+        return out
+
+
+PROFILER = None
+
+
+def _timed(kind, work, launch):
+    prof = PROFILER
+    if prof is None:
+        return launch()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    r = launch()
+    e.record()
+    prof.records.append((kind, float(work), s, e))
+    return r
+
+
+def _tile_tag(M, N, batch=1):
+    t = _lib.lib().sdamd_gemm_tile(M, N, batch)
+    return f"{t // 1000}x{t % 1000}"
+
+
+def _dt(dtype):
+    return "bf16" if dtype == torch.bfloat16 else "f32"
+
+
 _gn_ws = {}
 
 
@@ -107,8 +150,9 @@ def groupnorm(x, gamma, beta, eps, silu):
     assert gamma.numel() == C and beta.numel() == C
     y = torch.empty_like(x)
     ws = _groupnorm_ws(B, x.device)
-    _lib.check(_lib.lib().sdamd_groupnorm_nhwc(_p(x), _p(y), _p(gamma), _p(beta), _p(ws), B, HW, C, float(eps), int(silu),
-                                               _code(x.dtype), _stream()))
+    _timed(f"groupnorm_{_dt(x.dtype)}", 3 * x.numel() * x.element_size(),   # stats read + apply read + write
+           lambda: _lib.check(_lib.lib().sdamd_groupnorm_nhwc(_p(x), _p(y), _p(gamma), _p(beta), _p(ws), B, HW, C, float(eps),
+                                                              int(silu), _code(x.dtype), _stream())))
     return y
 
 
@@ -118,8 +162,9 @@ def layernorm(x, gamma, beta, eps=1e-5):
     C = x.shape[-1]
     assert gamma.numel() == C and beta.numel() == C
     y = torch.empty_like(x)
-    _lib.check(_lib.lib().sdamd_layernorm(_p(x), _p(y), _p(gamma), _p(beta), x.numel() // C, C, float(eps), _code(x.dtype),
-                                          _stream()))
+    _timed(f"layernorm_{_dt(x.dtype)}", 2 * x.numel() * x.element_size(),
+           lambda: _lib.check(_lib.lib().sdamd_layernorm(_p(x), _p(y), _p(gamma), _p(beta), x.numel() // C, C, float(eps),
+                                                         _code(x.dtype), _stream())))
     return y
 
 
@@ -140,7 +185,8 @@ def geglu(x):
     assert x.is_contiguous() and x.shape[-1] % 2 == 0
     Fh = x.shape[-1] // 2
     out = torch.empty(x.shape[:-1] + (Fh,), dtype=x.dtype, device=x.device)
-    _lib.check(_lib.lib().sdamd_geglu(_p(x), _p(out), x.numel() // (2 * Fh), Fh, _code(x.dtype), _stream()))
+    _timed(f"geglu_{_dt(x.dtype)}", (x.numel() + out.numel()) * x.element_size(),
+           lambda: _lib.check(_lib.lib().sdamd_geglu(_p(x), _p(out), x.numel() // (2 * Fh), Fh, _code(x.dtype), _stream())))
     return out
 
 
@@ -289,8 +335,9 @@ def gemm(a, w, bias=None, residual=None, act=ACT_NONE, out_f32=False):
         ldr = N
     if bias is not None:
         assert bias.dtype == torch.float32 and bias.numel() == N and bias.is_contiguous()
-    _lib.check(_lib.lib().sdamd_gemm(_p(a), _p(w), _p(out), _p(bias), _p(residual), M, N, K, lda, K, N, ldr, 1, 0, 0, 0, 0,
-                                     int(act), _code(a.dtype), int(out_f32), _stream()))
+    _timed(f"gemm_{_dt(a.dtype)}_{_tile_tag(M, N)}" if PROFILER is not None else "", 2.0 * M * N * K,
+           lambda: _lib.check(_lib.lib().sdamd_gemm(_p(a), _p(w), _p(out), _p(bias), _p(residual), M, N, K, lda, K, N, ldr, 1,
+                                                    0, 0, 0, 0, int(act), _code(a.dtype), int(out_f32), _stream())))
     return out
 
 
@@ -324,8 +371,11 @@ def conv3x3(x, w, bias, residual=None, stride=1, pad_mode=0, upsample=False, act
         assert residual.shape == out.shape and residual.dtype == x.dtype and residual.is_contiguous()
     if bias is not None:
         assert bias.dtype == torch.float32 and bias.numel() == Cout
-    _lib.check(_lib.lib().sdamd_conv3x3(_p(x), _p(w), _p(out), _p(bias), _p(residual), B, H, W, Cin, Cout, stride, pad_mode,
-                                        int(upsample), int(act), _code(x.dtype), int(out_f32), _stream()))
+    M = B * Ho * Wo
+    _timed(f"conv3x3_{_dt(x.dtype)}_{_tile_tag(M, Cout)}" if PROFILER is not None else "", 2.0 * M * Cout * 9 * Cin,
+           lambda: _lib.check(_lib.lib().sdamd_conv3x3(_p(x), _p(w), _p(out), _p(bias), _p(residual), B, H, W, Cin, Cout, stride,
+                                                       pad_mode, int(upsample), int(act), _code(x.dtype), int(out_f32),
+                                                       _stream())))
     return out
 
 
@@ -365,9 +415,11 @@ def attention(q, k, v, n_heads, causal=False):
     assert k.shape == (B, Skv, C) and v.shape == (B, Skv, C) and q.dtype == k.dtype == v.dtype
     assert q.stride(2) == 1 and k.stride(2) == 1 and v.stride(2) == 1
     out = torch.empty((B, Sq, C), dtype=q.dtype, device=q.device)
-    _lib.check(_lib.lib().sdamd_attention(_p(q), _p(k), _p(v), _p(out), B, n_heads, Sq, Skv, d,
-                                          q.stride(0), q.stride(1), k.stride(0), k.stride(1), v.stride(0), v.stride(1),
-                                          out.stride(0), out.stride(1), int(causal), _code(q.dtype), _stream()))
+    _timed(f"attention_{_dt(q.dtype)}_d{d}", 4.0 * B * n_heads * Sq * Skv * d,
+           lambda: _lib.check(_lib.lib().sdamd_attention(_p(q), _p(k), _p(v), _p(out), B, n_heads, Sq, Skv, d,
+                                                         q.stride(0), q.stride(1), k.stride(0), k.stride(1), v.stride(0),
+                                                         v.stride(1), out.stride(0), out.stride(1), int(causal),
+                                                         _code(q.dtype), _stream())))
     return out
 
 

@@ -99,9 +99,10 @@ class DenoiseLoop:
         self.latents.copy_(keep)
         self.counter.zero_()
 
-    def reset(self, latents):
+    def reset(self, latents, step=0):
+        """Restart from ``latents`` at schedule index ``step`` (teacher-forced parity tests)."""
         self.latents.copy_(latents)
-        self.counter.zero_()
+        self.counter.fill_(int(step))
 
     def step(self):
         if self.graph is not None:

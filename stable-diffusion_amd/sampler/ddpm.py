@@ -57,20 +57,26 @@ class DDPMSampler:
 
     def step_coefficients(self, timestep) -> torch.Tensor:
         """f32[8] = {sqrt(abar_t), sqrt(1-abar_t), c0, cx, sigma, has_noise, 0, 0}: the 0-dim
-        tensors of ddpm.py:59-83, evaluated with the same torch ops in the same order."""
+        tensors of ddpm.py:59-83, op for op, in numpy float32 scalar arithmetic.  (torch's scalar
+        ``** 0.5`` / ``sqrt`` is not correctly rounded on every host CPU -- 1-ulp differences were
+        measured between hosts -- whereas IEEE float32 here is portable and equals the reference's
+        values on the fixture host.)"""
+        f = np.float32
         t = int(timestep)
         prev_t = self._get_previous_timestep(t)
-        a_t = self.alpha_cumprod[t]
-        a_prev = self.alpha_cumprod[prev_t] if prev_t >= 0 else self.one
-        beta_cum_t = 1 - a_t
-        beta_cum_prev = 1 - a_prev
+        a_t = f(self.alpha_cumprod[t].item())
+        a_prev = f(self.alpha_cumprod[prev_t].item()) if prev_t >= 0 else f(1.0)
+        beta_cum_t = f(1) - a_t
+        beta_cum_prev = f(1) - a_prev
         cur_alpha = a_t / a_prev
-        cur_beta = 1 - cur_alpha
-        c0 = (a_prev ** 0.5 * cur_beta) / beta_cum_t
-        cx = cur_alpha ** 0.5 * beta_cum_prev / beta_cum_t
-        sigma = self._get_variance(t) ** 0.5 if t > 0 else torch.tensor(0.0)
-        return torch.stack([a_t ** 0.5, beta_cum_t ** 0.5, c0, cx, sigma,
-                            torch.tensor(1.0 if t > 0 else 0.0), torch.tensor(0.0), torch.tensor(0.0)]).float()
+        cur_beta = f(1) - cur_alpha
+        c0 = (np.sqrt(a_prev) * cur_beta) / beta_cum_t
+        cx = np.sqrt(cur_alpha) * beta_cum_prev / beta_cum_t
+        sigma = f(0)
+        if t > 0:
+            sigma = np.sqrt(np.maximum((f(1) - a_prev) / (f(1) - a_t) * (f(1) - a_t / a_prev), f(1e-20)))
+        vals = [np.sqrt(a_t), np.sqrt(beta_cum_t), c0, cx, sigma, f(1.0 if t > 0 else 0.0), f(0), f(0)]
+        return torch.from_numpy(np.asarray(vals, dtype=np.float32))
 
     def coefficient_table(self, timesteps=None) -> torch.Tensor:
         ts = self.timesteps if timesteps is None else timesteps
@@ -94,6 +100,6 @@ class DDPMSampler:
         return out
 
     def add_noise(self, original_samples: torch.Tensor, timesteps) -> torch.Tensor:
-        a = self.alpha_cumprod[int(timesteps)]
+        a = np.float32(self.alpha_cumprod[int(timesteps)].item())
         noise = self.draw_noise(tuple(original_samples.shape)).to(original_samples.device)
-        return ops.add_noise(original_samples.float(), noise, float(a ** 0.5), float((1 - a) ** 0.5))
+        return ops.add_noise(original_samples.float(), noise, float(np.sqrt(a)), float(np.sqrt(np.float32(1) - a)))

@@ -85,9 +85,12 @@ def gen_small():
             lat = hin(f"ddpm.lat.{t}", (1, 4, 16, 16), 2.0)
             eps = hin(f"ddpm.eps.{t}", (4, 16, 16), 1.5)
             out[f"step{steps}_{t}"] = sm.step(torch.tensor(t), lat, eps)
+            if t > 0:  # the noise the reference drew (CPU randn differs by ulps across host ISAs)
+                out[f"noise{steps}_{t}"] = torch.randn((4, 16, 16), generator=torch.Generator().manual_seed(1234 + t))
     g = torch.Generator().manual_seed(77)
     sm = RefDDPM(g); sm.set_steps(50)
     out["add_noise_780"] = sm.add_noise(hin("ddpm.an", (1, 4, 16, 16)), torch.tensor(780))
+    out["add_noise_780_noise"] = torch.randn((1, 4, 16, 16), generator=torch.Generator().manual_seed(77))
     save("ddpm_step", **out)
     # --- attention ops ---
     out = {}
@@ -195,9 +198,27 @@ def gen_pipeline(steps, name, every=1, **kw):
          n_steps=np.int64(len(tr.latents)))
 
 
+def gen_keys():
+    """state_dict key names + shapes of the reference modules: the weights ABI (loader.py:18-27)."""
+    out = {}
+    with torch.device("meta"):
+        mods = {"diffusion": quiet(ref_diffusion.Diffusion), "clip": quiet(ref_clip.CLIP),
+                "decoder": quiet(ref_decoder.VAE_Decoder), "encoder": quiet(ref_encoder.VAE_Encoder)}
+    for name, m in mods.items():
+        sd = m.state_dict()
+        shapes = -np.ones((len(sd), 4), dtype=np.int64)
+        for i, v in enumerate(sd.values()):
+            shapes[i, :v.dim()] = list(v.shape)
+        out[name + "_keys"] = np.array(list(sd.keys()))
+        out[name + "_shapes"] = shapes
+    save("state_dict_keys", **out)
+
+
 def main():
     what = set(sys.argv[1:]) or {"small", "models", "pipe3"}
     os.makedirs(GOLD, exist_ok=True)
+    if "keys" in what:
+        gen_keys()
     if "small" in what:
         gen_small()
     if "models" in what:
