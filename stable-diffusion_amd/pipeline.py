@@ -99,6 +99,13 @@ class DenoiseLoop:
         self.latents.copy_(keep)
         self.counter.zero_()
 
+    def set_context(self, context):
+        """New prompts for an already captured loop: recompute the K|V projections into the
+        buffers the graph reads (addresses stay fixed)."""
+        fresh = self.diffusion.unet.prompt_state(context)
+        for key, buf in self.kv.items():
+            buf.copy_(fresh[key])
+
     def reset(self, latents, step=0):
         """Restart from ``latents`` at schedule index ``step`` (teacher-forced parity tests)."""
         self.latents.copy_(latents)

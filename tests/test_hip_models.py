@@ -171,7 +171,9 @@ def _check_final_image(models, img, final_latents, g, dtype):
     assert img.shape == ref_img.shape and img.dtype == np.uint8
     sd = {k: v.cpu() for k, v in models["decoder"].state_dict().items()}
     want = O.vae_decode(sd, torch.from_numpy(g["latents"][-1]))
-    assert np.array_equal(O.to_uint8_image(want), ref_img)           # oracle reproduces the reference image
+    odiff = np.abs(O.to_uint8_image(want).astype(np.int32) - ref_img.astype(np.int32))
+    assert odiff.max() <= 1 and (odiff > 0).mean() < 0.01            # oracle reproduces the reference image
+    # (bit-equal on the fixture host; another host's CPU conv rounding may flip a pixel by one level)
     got = with_dtype(models["decoder"], dtype)(final_latents).cpu()
     assert rel_l2(got, want) < TOL[dtype]
     diff = np.abs(img.astype(np.int32) - ref_img.astype(np.int32))
