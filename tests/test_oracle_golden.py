@@ -10,7 +10,8 @@ from oracle import sd_oracle as O
 from conftest import golden, rel_l2, hin
 
 torch.set_grad_enabled(False)
-TOL = 1e-6
+TOL = 1e-6          # single ops / blocks
+TOL_MODEL = 1e-5    # whole networks: fp32 summation order varies with the CPU thread count / oneDNN algorithm
 
 
 def hashed(shapes, prefix):
@@ -77,3 +78,81 @@ def test_attention_ops():
         sd = {"a." + k: v for k, v in sd.items()}
         out = O.cross_attention(sd, "a", hin(f"cross.x.{tag}", (2, seq, dim)), hin(f"cross.y.{tag}", (2, 77, 768)), heads)
         assert rel_l2(out, g["cross_" + tag]) < TOL, tag
+
+
+# ------------------------------------------------------------------ blocks / models / pipeline
+def _shapes(prefix_filter, model):
+    keys = golden("state_dict_keys")
+    names, shapes = keys[model + "_keys"].tolist(), keys[model + "_shapes"]
+    return {k: tuple(int(x) for x in s[s >= 0]) for k, s in zip(names, shapes) if k.startswith(prefix_filter)}
+
+
+def _block_sd(model, inner_prefix, hash_prefix):
+    """state_dict of one block: shapes taken from the reference's key list, values hashed under
+    the block's own prefix (as tools/gen_golden.py did for the stand-alone reference block)."""
+    shapes = {k[len(inner_prefix):]: s for k, s in _shapes(inner_prefix, model).items()}
+    return {"b." + k: v for k, v in synth.hash_state_dict(shapes, hash_prefix).items()}
+
+
+def test_blocks():
+    g = golden("blocks")
+    sd = _block_sd("diffusion", "unet.encoders.1.0.", "blk.res2.")
+    out = O.unet_residual_block(sd, "b", hin("blk.res2.x", (2, 320, 8, 8)), hin("blk.res2.t", (1, 1280)))
+    assert rel_l2(out, g["unet_res_320_320"]) < TOL
+    sd = _block_sd("diffusion", "unet.encoders.1.1.", "blk.attn.")
+    out = O.unet_attention_block(sd, "b", hin("blk.attn.x", (2, 320, 8, 8)), hin("blk.attn.ctx", (2, 77, 768)))
+    assert rel_l2(out, g["unet_attn_8x40"]) < TOL
+    sd = _block_sd("decoder", "3.", "blk.vattn.")
+    assert rel_l2(O.vae_attention_block(sd, "b", hin("blk.vattn.x", (1, 512, 8, 8))), g["vae_attn_512"]) < TOL
+    sd = _block_sd("decoder", "20.", "blk.vres.")   # VAE_ResidualBlock(256, 128) has the other orientation;
+    shapes = {"groupnorm_1.weight": (128,), "groupnorm_1.bias": (128,), "conv_1.weight": (256, 128, 3, 3), "conv_1.bias": (256,),
+              "groupnorm_2.weight": (256,), "groupnorm_2.bias": (256,), "conv_2.weight": (256, 256, 3, 3), "conv_2.bias": (256,),
+              "residual_layer.weight": (256, 128, 1, 1), "residual_layer.bias": (256,)}
+    sd = {"b." + k: v for k, v in synth.hash_state_dict(shapes, "blk.vres.").items()}
+    assert rel_l2(O.vae_residual_block(sd, "b", hin("blk.vres.x", (1, 128, 16, 16))), g["vae_res_128_256"]) < TOL
+
+
+@pytest.fixture(scope="module")
+def model_sds():
+    return {m: synth.hash_state_dict(_shapes("", m), m + ".") for m in ("clip", "decoder", "encoder")}
+
+
+@pytest.fixture(scope="module")
+def diffusion_sd():
+    return synth.hash_state_dict(_shapes("", "diffusion"), "diffusion.")
+
+
+def test_clip_model(model_sds):
+    g = golden("clip")
+    assert rel_l2(O.clip_forward(model_sds["clip"], torch.from_numpy(g["tokens"])), g["out"]) < TOL_MODEL
+
+
+def test_vae_models(model_sds):
+    g = golden("vae_decoder")
+    assert rel_l2(O.vae_decode(model_sds["decoder"], hin("dec.lat.8", (2, 4, 8, 8), 0.5)), g["dec8"]) < TOL_MODEL
+    g = golden("vae_encoder")
+    out = O.vae_encode(model_sds["encoder"], hin("enc.img.64", (2, 3, 64, 64)), hin("enc.noise.64", (2, 4, 8, 8)))
+    assert rel_l2(out, g["enc64"]) < TOL_MODEL
+
+
+@pytest.mark.slow
+def test_diffusion_model(diffusion_sd):
+    """BASELINE config 2 on the oracle side: Diffusion forward, UNet batch 2, latent 16^2 and 64^2."""
+    g = golden("diffusion")
+    ctx = torch.from_numpy(golden("clip")["out"])
+    for hw, t in ((16, 500), (64, 980)):
+        out = O.diffusion_forward(diffusion_sd, hin(f"diff.lat.{hw}", (2, 4, hw, hw), 2.0), ctx, O.get_time_embedding(t))
+        assert rel_l2(out, g[f"out{hw}"]) < TOL_MODEL, hw
+
+
+@pytest.mark.slow
+def test_pipeline_txt2img_3step(model_sds, diffusion_sd):
+    """Oracle generate() vs the reference's pipeline.generate (3 steps, 512^2, CFG 7.5, seed 42)."""
+    g = golden("pipeline_txt2img_3step")
+    models = dict(model_sds, diffusion=diffusion_sd)
+    trace = []
+    img = O.generate(models, synth.synthetic_token_ids(0), synth.EMPTY_PROMPT_IDS, seed=42, steps=3, trace=trace)
+    for i in range(3):
+        assert rel_l2(trace[i], g["latents"][i]) < TOL_MODEL, i
+    diff = np.abs(img.astype(np.int32) - g["image"].astype(np.int32))
+    assert diff.max() <= 1 and (diff > 0).mean() < 0.01
