@@ -1,8 +1,8 @@
 // MFMA flash attention for gfx950 -- replaces the eager softmax(QK^T)V of attention.py:47-68,
 // 112-127 and the Triton path (customtriton.py, flash_attention.py) of the reference.
 // No S x S matrix is materialised: one workgroup = 4 waves = 128 query rows of one (batch, head);
-// each wave owns 32 query rows and sweeps the keys in LDS-staged tiles of 32 with an online
-// softmax.  Scores are computed transposed, S^T = K Q^T (32x32 MFMA, key on the accumulator row,
+// each wave owns 32 query rows and sweeps the keys in LDS-staged, double-buffered tiles (64 keys
+// bf16 / 32 keys f32, next tile prefetched through registers) with an online softmax.  Scores are computed transposed, S^T = K Q^T (32x32 MFMA, key on the accumulator row,
 // query on the lane), so a query's running max / sum are lane-local (one cross-half exchange)
 // and the exponentiated tile is already the B operand of the O^T += V^T P^T MFMAs.
 //   bf16: v_mfma_f32_32x32x16_bf16; V^T fragments come from row-major V in LDS through
@@ -34,26 +34,32 @@ template <int D> struct AttnCfg<bf16_t, D> {
   static constexpr int DV = (D + 31) / 32 * 32;
   static constexpr int KS = DK * 2 + 16;                             // K row stride (bytes): odd multiple of 16
   static constexpr int VS = (DV * 2) % 256 == 64 || (DV * 2) % 256 == 192 ? DV * 2 : DV * 2 + 64;  // 4 rows x 64 B tile a bank row
+  static constexpr int BKV = 64;                                     // keys per staged tile
+  static constexpr int STAGE = BKV * (KS + VS);
 };
 template <int D> struct AttnCfg<float, D> {
   static constexpr int DK = D;  // multiple of 8
   static constexpr int DV = (D + 31) / 32 * 32;
   static constexpr int KS = DK * 4 + 16;
   static constexpr int VS = DV * 4;
+  static constexpr int BKV = 32;   // f32 tiles are twice as wide in bytes: 2 stages of 64 keys would not fit at d=160
+  static constexpr int STAGE = BKV * (KS + VS);
 };
 
 template <typename T, int D>
 __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs p) {
   typedef AttnCfg<T, D> Cfg;
-  constexpr int DK = Cfg::DK, DV = Cfg::DV, KS = Cfg::KS, VS = Cfg::VS;
+  constexpr int DK = Cfg::DK, DV = Cfg::DV, KS = Cfg::KS, VS = Cfg::VS, BKV = Cfg::BKV;
   constexpr int EPC = 16 / sizeof(T);
   constexpr int KC = DK / EPC, VC = DV / EPC, DC = D / EPC;  // 16-byte chunks per row
   constexpr int NB = DV / 32;                                // 32-wide output blocks
+  constexpr int NSUB = BKV / 32;                             // 32-key sub-tiles per staged tile
   constexpr bool BF = sizeof(T) == 2;
   constexpr int NQ = BF ? DK / 16 : D / 8;                   // Q fragments (4 VGPR each)
-  __shared__ __attribute__((aligned(16))) char smem[32 * KS + 32 * VS];
-  char* ks = smem;
-  char* vs = smem + 32 * KS;
+  constexpr int KCH = BKV * KC, VCH = BKV * VC;              // chunks per staged tile
+  constexpr int KPT = (KCH + 255) / 256, VPT = (VCH + 255) / 256;
+  constexpr int STAGE = Cfg::STAGE;
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 stages of [K tile | V tile]
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int r = lane & 31, h = lane >> 5;
@@ -77,120 +83,170 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs p) {
     }
   }
 
+  // register-staged K/V tile: loads for tile t+1 are issued before tile t is computed and
+  // written to the other LDS stage afterwards (pad columns and rows >= Skv are zero-filled)
+  u32x4_t rk[KPT], rv[VPT];
+  auto issue = [&](int kv0) {
+#pragma unroll
+    for (int i = 0; i < KPT; ++i) {
+      const int c = t + 256 * i;
+      const int row = c / KC, ch = c - row * KC;
+      u32x4_t z = {0u, 0u, 0u, 0u};
+      if (c < KCH && ch < DC && kv0 + row < p.Skv) z = *reinterpret_cast<const u32x4_t*>(Kp + (size_t)(kv0 + row) * p.k_rs + ch * EPC);
+      rk[i] = z;
+    }
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {
+      const int c = t + 256 * i;
+      const int row = c / VC, ch = c - row * VC;
+      u32x4_t z = {0u, 0u, 0u, 0u};
+      if (c < VCH && ch < DC && kv0 + row < p.Skv) z = *reinterpret_cast<const u32x4_t*>(Vp + (size_t)(kv0 + row) * p.v_rs + ch * EPC);
+      rv[i] = z;
+    }
+  };
+  auto commit = [&](int stage) {
+    char* ks = smem + stage * STAGE;
+    char* vs = ks + BKV * KS;
+#pragma unroll
+    for (int i = 0; i < KPT; ++i) {
+      const int c = t + 256 * i;
+      const int row = c / KC, ch = c - row * KC;
+      if (c < KCH) *reinterpret_cast<u32x4_t*>(ks + row * KS + ch * 16) = rk[i];
+    }
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {
+      const int c = t + 256 * i;
+      const int row = c / VC, ch = c - row * VC;
+      if (c < VCH) *reinterpret_cast<u32x4_t*>(vs + row * VS + ch * 16) = rv[i];
+    }
+  };
+
   f32x16_t o[NB];
 #pragma unroll
   for (int i = 0; i < NB; ++i)
 #pragma unroll
     for (int e = 0; e < 16; ++e) o[i][e] = 0.f;
-  float m_run = -1.0e30f, l_run = 0.f;
+  float m_run = -1.0e30f, l_run = 0.f;  // running max (scaled, log2 domain) and denominator
 
   // causal: this block needs keys 0 .. q0_block+127 only
   int kv_end = p.Skv;
   if (p.causal) kv_end = min(p.Skv, (int)blockIdx.x * 128 + 128);
-  const int ntiles = (kv_end + 31) / 32;
+  const int ntiles = (kv_end + BKV - 1) / BKV;
+  const float sc = p.scale_log2e;
 
+  issue(0);
+  commit(0);
+  __syncthreads();
   for (int kt = 0; kt < ntiles; ++kt) {
-    const int kv0 = kt * 32;
-    __syncthreads();  // previous tile fully consumed
-    // stage K (32 x DK) and V (32 x DV), zero-filling pad columns and rows >= Skv
-    for (int c = t; c < 32 * KC; c += 256) {
-      int row = c / KC, ch = c - row * KC;
-      u32x4_t z = {0u, 0u, 0u, 0u};
-      if (ch < DC && kv0 + row < p.Skv) z = *reinterpret_cast<const u32x4_t*>(Kp + (size_t)(kv0 + row) * p.k_rs + ch * EPC);
-      *reinterpret_cast<u32x4_t*>(ks + row * KS + ch * 16) = z;
-    }
-    for (int c = t; c < 32 * VC; c += 256) {
-      int row = c / VC, ch = c - row * VC;
-      u32x4_t z = {0u, 0u, 0u, 0u};
-      if (ch < DC && kv0 + row < p.Skv) z = *reinterpret_cast<const u32x4_t*>(Vp + (size_t)(kv0 + row) * p.v_rs + ch * EPC);
-      *reinterpret_cast<u32x4_t*>(vs + row * VS + ch * 16) = z;
-    }
-    __syncthreads();
+    const int kv0 = kt * BKV;
+    const char* ks = smem + (kt & 1) * STAGE;
+    const char* vs = ks + BKV * KS;
+    if (kt + 1 < ntiles) issue(kv0 + BKV);
 
     // S^T = K Q^T : rows = keys (accumulator registers), cols = queries (lanes)
-    f32x16_t s;
+    f32x16_t s[NSUB];
 #pragma unroll
-    for (int e = 0; e < 16; ++e) s[e] = 0.f;
-    if constexpr (BF) {
+    for (int sub = 0; sub < NSUB; ++sub) {
 #pragma unroll
-      for (int st = 0; st < NQ; ++st) {
-        bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(ks + r * KS + (16 * st + 8 * h) * 2);
-        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, __builtin_bit_cast(bf16x8_t, qf[st]), s, 0, 0, 0);
-      }
-    } else {
+      for (int e = 0; e < 16; ++e) s[sub][e] = 0.f;
+      if constexpr (BF) {
 #pragma unroll
-      for (int g = 0; g < NQ; ++g) {
-        f32x4_t kf = *reinterpret_cast<const f32x4_t*>(ks + r * KS + (8 * g + 4 * h) * 4);
-        f32x4_t qv = __builtin_bit_cast(f32x4_t, qf[g]);
+        for (int st = 0; st < NQ; ++st) {
+          bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(ks + (sub * 32 + r) * KS + (16 * st + 8 * h) * 2);
+          s[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, __builtin_bit_cast(bf16x8_t, qf[st]), s[sub], 0, 0, 0);
+        }
+      } else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[e], qv[e], s, 0, 0, 0);
+        for (int g = 0; g < NQ; ++g) {
+          f32x4_t kf = *reinterpret_cast<const f32x4_t*>(ks + (sub * 32 + r) * KS + (8 * g + 4 * h) * 4);
+          f32x4_t qv = __builtin_bit_cast(f32x4_t, qf[g]);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) s[sub] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[e], qv[e], s[sub], 0, 0, 0);
+        }
       }
     }
 
-    // mask + online softmax (base-2 domain)
+    // mask (boundary / causal tiles only; wave-uniform branch) + online softmax in the log2 domain
+    if (kv0 + BKV > p.Skv || p.causal) {
+#pragma unroll
+      for (int sub = 0; sub < NSUB; ++sub)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int key = kv0 + sub * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+          if (key >= p.Skv || (p.causal && key > qrow)) s[sub][e] = -1.0e30f;
+        }
+    }
     float mx = -1.0e30f;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int key = kv0 + (e & 3) + 8 * (e >> 2) + 4 * h;
-      float v = s[e] * p.scale_log2e;
-      if (key >= p.Skv || (p.causal && key > qrow)) v = -1.0e30f;
-      s[e] = v;
-      mx = fmaxf(mx, v);
-    }
+    for (int sub = 0; sub < NSUB; ++sub)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) mx = fmaxf(mx, s[sub][e]);
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx);
-    const float alpha = exp2f(m_run - m_new);
+    const float m_new = fmaxf(m_run, mx * sc);
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
     float rs = 0.f;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      float pe = exp2f(s[e] - m_new);
-      s[e] = pe;
-      rs += pe;
-    }
+    for (int sub = 0; sub < NSUB; ++sub)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const float pe = __builtin_amdgcn_exp2f(fmaf(s[sub][e], sc, -m_new));
+        s[sub][e] = pe;
+        rs += pe;
+      }
     rs += __shfl_xor(rs, 32, 64);
-    l_run = l_run * alpha + rs;
+    l_run = fmaf(l_run, alpha, rs);
     m_run = m_new;
+    if (!__all(alpha == 1.0f)) {  // exact: skip the O rescale when no row of this wave got a new max
 #pragma unroll
-    for (int i = 0; i < NB; ++i)
+      for (int i = 0; i < NB; ++i)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) o[i][e] *= alpha;
+        for (int e = 0; e < 16; ++e) o[i][e] *= alpha;
+    }
 
     // O^T += V^T P^T
     if constexpr (BF) {
-      bf16x8_t pf[2];
-#pragma unroll
-      for (int st = 0; st < 2; ++st) {
-        u32x4_t w;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) w[j] = pack_bf2(s[8 * st + 2 * j], s[8 * st + 2 * j + 1]);
-        pf[st] = __builtin_bit_cast(bf16x8_t, w);
-      }
       // transpose read: lane 4q+p of each 16-lane group addresses row q, columns 4p..4p+3 of a
       // 4-key x 16-column block; element j of the A fragment is key 16*st + 8*(j>>2) + 4h + (j&3)
       const int g16 = lane >> 4, li = lane & 15;
       const char* vbase = vs + (4 * (g16 >> 1) + (li >> 2)) * VS + (16 * (g16 & 1) + 4 * (li & 3)) * 2;
 #pragma unroll
-      for (int i = 0; i < NB; ++i) {
+      for (int sub = 0; sub < NSUB; ++sub) {
+        bf16x8_t pf[2];
 #pragma unroll
         for (int st = 0; st < 2; ++st) {
-          s16x4_t lo = lds_read_tr16(vbase + (16 * st) * VS + i * 64);
-          s16x4_t hi = lds_read_tr16(vbase + (16 * st + 8) * VS + i * 64);
-          typedef __attribute__((ext_vector_type(8))) short s16x8_t;
-          s16x8_t vv = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-          o[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, vv), pf[st], o[i], 0, 0, 0);
+          u32x4_t w;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) w[j] = pack_bf2(s[sub][8 * st + 2 * j], s[sub][8 * st + 2 * j + 1]);
+          pf[st] = __builtin_bit_cast(bf16x8_t, w);
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+#pragma unroll
+          for (int st = 0; st < 2; ++st) {
+            s16x4_t lo = lds_read_tr16(vbase + (sub * 32 + 16 * st) * VS + i * 64);
+            s16x4_t hi = lds_read_tr16(vbase + (sub * 32 + 16 * st + 8) * VS + i * 64);
+            typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+            s16x8_t vv = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            o[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, vv), pf[st], o[i], 0, 0, 0);
+          }
         }
       }
     } else {
 #pragma unroll
-      for (int i = 0; i < NB; ++i) {
+      for (int sub = 0; sub < NSUB; ++sub)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int key = (e & 3) + 8 * (e >> 2) + 4 * h;
-          float a = *reinterpret_cast<const float*>(vs + key * VS + (i * 32 + r) * 4);
-          o[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, s[e], o[i], 0, 0, 0);
+        for (int i = 0; i < NB; ++i) {
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int key = sub * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+            float a = *reinterpret_cast<const float*>(vs + key * VS + (i * 32 + r) * 4);
+            o[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, s[sub][e], o[i], 0, 0, 0);
+          }
         }
-      }
     }
+
+    if (kt + 1 < ntiles) commit((kt + 1) & 1);
+    __syncthreads();
   }
 
   // epilogue: O[q][d] = O^T[d][q] / l ; lane holds d = 32i + 8*(e>>2) + 4h + (e&3)
@@ -219,7 +275,13 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs p) {
 template <typename T, int D>
 static int launch_attn(const AttnArgs& a, int B, hipStream_t st) {
   dim3 grid((a.Sq + 127) / 128, B * a.H);
-  attn_kernel<T, D><<<grid, 256, 0, st>>>(a);
+  constexpr int lds = 2 * AttnCfg<T, D>::STAGE;
+  static bool attr_set = false;
+  if (!attr_set && lds > 48 * 1024) {
+    (void)hipFuncSetAttribute((const void*)attn_kernel<T, D>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_set = true;
+  }
+  attn_kernel<T, D><<<grid, 256, lds, st>>>(a);
   SD_LAUNCH_CHECK("attention");
   return 0;
 }

@@ -75,30 +75,39 @@ __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const T* __restric
   }
 }
 
-// GroupNorm apply (+ optional SiLU): grid (nblk2, B).  Each block first reduces the nblk_stats
-// partials of image n into mean/rstd for its 32 groups, then streams its pixel range.
+// GroupNorm finalize: grid B, 32 threads.  Reduces the per-block partials of image n (fixed order)
+// into mean / rstd per group: fin[n][g] = {mean, rstd} (f32).
+__global__ __launch_bounds__(64) void gn_finalize_kernel(const double* __restrict__ ws, float* __restrict__ fin,
+                                                         int nblk_stats, int HW, int cpg, float eps) {
+  const int n = blockIdx.x, t = threadIdx.x;
+  if (t >= 32) return;
+  double ss = 0.0, qq = 0.0;
+  for (int b = 0; b < nblk_stats; ++b) {
+    const double* src = ws + (((size_t)n * nblk_stats + b) * 32 + t) * 2;
+    ss += src[0]; qq += src[1];
+  }
+  const double cnt = (double)HW * cpg;
+  const double mean = ss / cnt;
+  double var = qq / cnt - mean * mean;
+  if (var < 0.0) var = 0.0;
+  fin[((size_t)n * 32 + t) * 2 + 0] = (float)mean;
+  fin[((size_t)n * 32 + t) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+// GroupNorm apply (+ optional SiLU): grid (nblk2, B); pure streaming pass, 16-byte vectors.
 template <typename T>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, T* __restrict__ y,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                       const double* __restrict__ ws, int nblk_stats, int HW, int C,
-                                                       float eps, int silu, int pix_per_blk) {
+                                                       const float* __restrict__ fin, int HW, int C, int silu,
+                                                       int pix_per_blk) {
   constexpr int V = 16 / sizeof(T);
   __shared__ float s_mean[32], s_rstd[32];
   const int n = blockIdx.y;
   const int t = threadIdx.x;
   const int cpg = C / 32;
   if (t < 32) {
-    double ss = 0.0, qq = 0.0;
-    for (int b = 0; b < nblk_stats; ++b) {
-      const double* src = ws + (((size_t)n * nblk_stats + b) * 32 + t) * 2;
-      ss += src[0]; qq += src[1];
-    }
-    double cnt = (double)HW * cpg;
-    double mean = ss / cnt;
-    double var = qq / cnt - mean * mean;
-    if (var < 0.0) var = 0.0;
-    s_mean[t] = (float)mean;
-    s_rstd[t] = (float)(1.0 / sqrt(var + (double)eps));
+    s_mean[t] = fin[((size_t)n * 32 + t) * 2 + 0];
+    s_rstd[t] = fin[((size_t)n * 32 + t) * 2 + 1];
   }
   __syncthreads();
   const int vpp = C / V;  // vectors per pixel
@@ -106,20 +115,31 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
   const int p1 = min(HW, p0 + pix_per_blk);
   const size_t img = (size_t)n * HW * C;
   const int nvec = (p1 - p0) * vpp;
+  const float inv_cpg = 1.0f / (float)cpg;
+  const int dp = 256 / vpp, dcv = 256 % vpp;
+  int p = p0 + t / vpp, cv = t % vpp;
   for (int i = t; i < nvec; i += 256) {
-    int p = p0 + i / vpp, cv = i % vpp;
-    size_t off = img + (size_t)p * C + (size_t)cv * V;
+    const size_t off = img + (size_t)p * C + (size_t)cv * V;
     float v[V];
     load_vec<T>(x + off, v);
-    int g = (cv * V) / cpg, rem = cv * V - g * cpg;
+    const int c0 = cv * V;
+    f32x4_t gm[V / 4], bt[V / 4];
+#pragma unroll
+    for (int k = 0; k < V / 4; ++k) {
+      gm[k] = *reinterpret_cast<const f32x4_t*>(gamma + c0 + 4 * k);
+      bt[k] = *reinterpret_cast<const f32x4_t*>(beta + c0 + 4 * k);
+    }
+    int g = (int)(((float)c0 + 0.5f) * inv_cpg);   // exact: (c+0.5)/cpg is never within rounding of an integer
+    int rem = c0 - g * cpg;
 #pragma unroll
     for (int j = 0; j < V; ++j) {
-      int c = cv * V + j;
-      float r = (v[j] - s_mean[g]) * s_rstd[g] * gamma[c] + beta[c];
+      float r = (v[j] - s_mean[g]) * s_rstd[g] * gm[j >> 2][j & 3] + bt[j >> 2][j & 3];
       v[j] = silu ? silu_f(r) : r;
       if (++rem == cpg) { rem = 0; ++g; }
     }
     store_vec<T>(y + off, v);
+    p += dp; cv += dcv;
+    if (cv >= vpp) { cv -= vpp; ++p; }
   }
 }
 
@@ -216,7 +236,8 @@ static int gn_geometry(int C, int V, int* tpp, int* nchunk) {
   return 0;
 }
 
-extern "C" size_t sdamd_groupnorm_ws_bytes(int B) { return (size_t)B * 64 * 32 * 2 * sizeof(double); }
+// workspace: per-block partials [B][64][32][2] f64, then finalized {mean, rstd} [B][32][2] f32
+extern "C" size_t sdamd_groupnorm_ws_bytes(int B) { return (size_t)B * (64 * 32 * 2 * sizeof(double) + 32 * 2 * sizeof(float)); }
 
 extern "C" int sdamd_groupnorm_nhwc(const void* x, void* y, const float* gamma, const float* beta, void* ws, int B,
                                     int HW, int C, float eps, int silu, int dtype, void* stream) {
@@ -246,16 +267,22 @@ extern "C" int sdamd_groupnorm_nhwc(const void* x, void* y, const float* gamma, 
     gn_stats_kernel<float><<<grid, GN_THREADS, lds, st>>>((const float*)x, (double*)ws, HW, C, tpp, nchunk, ppb);
   }
   SD_LAUNCH_CHECK("gn_stats");
-  // apply: ~2K vectors (32 KB) per block
+  float* fin = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + (size_t)B * 64 * 32 * 2 * sizeof(double));
+  gn_finalize_kernel<<<B, 64, 0, st>>>((const double*)ws, fin, nblk, HW, C / 32, eps);
+  SD_LAUNCH_CHECK("gn_finalize");
+  // apply: ~4K vectors (64 KB) per block, but keep >= ~1024 blocks in flight
   int vpp = C / V;
-  int ppb2 = (2048 + vpp - 1) / vpp;
+  long long total_vec = (long long)B * HW * vpp;
+  int vec_per_blk = 4096;
+  while (vec_per_blk > 512 && total_vec / vec_per_blk < 1024) vec_per_blk >>= 1;
+  int ppb2 = (vec_per_blk + vpp - 1) / vpp;
   if (ppb2 < 1) ppb2 = 1;
   int nblk2 = (HW + ppb2 - 1) / ppb2;
   dim3 grid2(nblk2, B);
   if (dtype == SDAMD_BF16)
-    gn_apply_kernel<bf16_t><<<grid2, 256, 0, st>>>((const bf16_t*)x, (bf16_t*)y, gamma, beta, (const double*)ws, nblk, HW, C, eps, silu, ppb2);
+    gn_apply_kernel<bf16_t><<<grid2, 256, 0, st>>>((const bf16_t*)x, (bf16_t*)y, gamma, beta, fin, HW, C, silu, ppb2);
   else
-    gn_apply_kernel<float><<<grid2, 256, 0, st>>>((const float*)x, (float*)y, gamma, beta, (const double*)ws, nblk, HW, C, eps, silu, ppb2);
+    gn_apply_kernel<float><<<grid2, 256, 0, st>>>((const float*)x, (float*)y, gamma, beta, fin, HW, C, silu, ppb2);
   SD_LAUNCH_CHECK("gn_apply");
   return 0;
 }

@@ -232,7 +232,7 @@ def main():
         # literal reference semantics: start_step = 1000 - int(1000*0.998) = 2 -> 3 of 5 steps
         gen_pipeline(5, "pipeline_img2img_5step_s0998", input_image=pil, strength=0.998)
     if "pipe50" in what:
-        gen_pipeline(50, "pipeline_txt2img_50step", every=5)
+        gen_pipeline(50, "pipeline_txt2img_50step", every=1)
 
 
 if __name__ == "__main__":
