@@ -45,7 +45,8 @@ def build_models(device, dtype, keep_cpu):
         m = synth.load_hashed(cls(), name + ".")
         if keep_cpu:
             cpu_sd[name] = {k: v.clone() for k, v in m.state_dict().items()}
-        models[name] = engine.set_compute_dtype(m.to(device), dtype)
+        # text encoder on the f32 kernels, as pipeline.generate runs it (see pipeline.py)
+        models[name] = engine.set_compute_dtype(m.to(device), torch.float32 if name == "clip" else dtype)
     return models, cpu_sd
 
 
@@ -195,13 +196,11 @@ def main():
         extra["kernel_breakdown"] = rows[:12]
     if world == 1 and not args.skip_fp32_latency:   # BASELINE config 2: UNET step, UNet batch 2, fp32
         engine.set_compute_dtype(models["diffusion"], torch.float32)
-        engine.set_compute_dtype(models["clip"], torch.float32)
         j2 = Txt2ImgJob(models, 0, 1, args.denoise_steps, 7.5, device)
         extra["unet_step_ms_fp32_b2"] = round(unet_step_ms(j2.loop, j2.latents0), 3)
         extra["unet_step_fp32_b2_tflops"] = round(1.6065 / (extra["unet_step_ms_fp32_b2"] * 1e-3), 1)
         del j2
         engine.set_compute_dtype(models["diffusion"], dtype)
-        engine.set_compute_dtype(models["clip"], dtype)
     if cpu_sd:
         result["cpu_baseline"] = cpu_baseline_leg(cpu_sd)
     result["extra"] = extra

@@ -50,13 +50,16 @@ int sdamd_gather_row(float* dst, const float* table, const int* step_ptr, int st
                      void* stream);
 
 /* ---- normalisation: nn.GroupNorm(32,C)(+F.silu) diffusion.py:26-28,38-40,93,292-294,
- * decoder.py:25-30,49,118-120; x,y NHWC [B][HW][C]; ws >= sdamd_groupnorm_ws_bytes(B). */
+ * decoder.py:25-30,49,118-120; x,y NHWC [B][HW][C]; ws >= sdamd_groupnorm_ws_bytes(B).
+ * x is `dtype`, y is `out_dtype` (f32->f32, bf16->bf16, or f32->bf16: an f32 residual trunk
+ * normalised straight into a bf16 MFMA operand). */
 size_t sdamd_groupnorm_ws_bytes(int B);
 int sdamd_groupnorm_nhwc(const void* x, void* y, const float* gamma, const float* beta, void* ws,
-                         int B, int HW, int C, float eps, int silu, int dtype, void* stream);
-/* nn.LayerNorm(C): diffusion.py:109,117,126; clip.py:54,63,95 */
+                         int B, int HW, int C, float eps, int silu, int dtype, int out_dtype,
+                         void* stream);
+/* nn.LayerNorm(C): diffusion.py:109,117,126; clip.py:54,63,95; dtypes as for groupnorm */
 int sdamd_layernorm(const void* x, void* y, const float* gamma, const float* beta, int rows, int C,
-                    float eps, int dtype, void* stream);
+                    float eps, int dtype, int out_dtype, void* stream);
 /* softmax(scores*scale) per row, f32 in, dtype out (unfused d_head=512 VAE attention) */
 int sdamd_softmax_rows(const float* scores, void* probs, int rows, int n, float scale, int dtype,
                        void* stream);
@@ -74,6 +77,11 @@ int sdamd_add(const void* a, const void* b, void* out, long long numel, int dtyp
 int sdamd_nchw_to_nhwc(const float* src, void* dst, int B, int C, int HW, int dtype, void* stream);
 int sdamd_nhwc_to_nchw(const void* src, float* dst, int B, int C, int HW, int dtype, void* stream);
 int sdamd_cast(const void* src, void* dst, long long n, int src_dtype, int dst_dtype, void* stream);
+/* dst [rows][2K] bf16 = [bf16(x) | bf16(x - bf16(x))]: two-term bf16 split of an f32 GEMM operand.
+ * Used with weights laid out [W | W] where the un-normalised f32 residual trunk itself is the
+ * operand (1x1 skip convs diffusion.py:18,42; conv_output diffusion.py:85,140), so that bf16
+ * MFMA does not round the trunk (no reference counterpart: the reference computes these in f32) */
+int sdamd_split_hilo(const float* src, void* dst, long long rows, int K, void* stream);
 /* F.silu on an f32 vector (diffusion.py:32) */
 int sdamd_silu(const float* src, float* dst, long long n, void* stream);
 int sdamd_transpose(const void* src, void* dst, int batch, int rows, int cols, int ld_src,
@@ -91,7 +99,8 @@ int sdamd_vae_sample(const float* x, const float* noise, float* out, const float
 
 /* ---- MFMA GEMM: nn.Linear / conv1x1 (attention.py:19-20,81-85; diffusion.py:18,54,82-85,
  * 156-157; clip.py:45-46).  C[m][n] = act(sum_k A[m][k]*W[n][k] + bias[n] + residual[m][n]);
- * K % 64 == 0, N % 16 == 0; `batch` independent problems with element strides. */
+ * K % 64 == 0, N % 16 == 0; `batch` independent problems with element strides.  C and the
+ * residual share one type: f32 when out_f32 (or dtype f32), else bf16. */
 int sdamd_gemm(const void* A, const void* W, void* C, const float* bias, const void* residual, int M,
                int N, int K, int lda, int ldw, int ldc, int ldr, int batch, long long strideA,
                long long strideW, long long strideC, long long strideR, int act, int dtype,

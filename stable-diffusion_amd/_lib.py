@@ -20,8 +20,8 @@ SIGNATURES = {
     "sdamd_add_noise": (_i, [_vp, _vp, _vp, _f, _f, _ll, _vp]),
     "sdamd_gather_row": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
     "sdamd_groupnorm_ws_bytes": (_sz, [_i]),
-    "sdamd_groupnorm_nhwc": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _i, _vp]),
-    "sdamd_layernorm": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _i, _vp]),
+    "sdamd_groupnorm_nhwc": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _i, _i, _vp]),
+    "sdamd_layernorm": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _i, _i, _vp]),
     "sdamd_softmax_rows": (_i, [_vp, _vp, _i, _i, _f, _i, _vp]),
     "sdamd_geglu": (_i, [_vp, _vp, _ll, _i, _i, _vp]),
     "sdamd_clip_embed": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
@@ -30,6 +30,7 @@ SIGNATURES = {
     "sdamd_nchw_to_nhwc": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "sdamd_nhwc_to_nchw": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "sdamd_cast": (_i, [_vp, _vp, _ll, _i, _i, _vp]),
+    "sdamd_split_hilo": (_i, [_vp, _vp, _ll, _i, _vp]),
     "sdamd_silu": (_i, [_vp, _vp, _ll, _vp]),
     "sdamd_transpose": (_i, [_vp, _vp, _i, _i, _i, _i, _ll, _ll, _i, _vp]),
     "sdamd_image_to_uint8": (_i, [_vp, _vp, _i, _i, _vp]),

@@ -11,19 +11,23 @@ _ATTENTION_TYPES = ("xformers", "flashattention", "default")
 
 
 class CLIPEmbedding(engine.HipModule):
+    f32_trunk = True
+
     def __init__(self, vocab_size, n_embeddings, n_tokens: int):
         super().__init__()
         self.token_embedding = nn.Embedding(vocab_size, n_embeddings)
         self.position_embedding = nn.Parameter(torch.zeros(n_tokens, n_embeddings))
 
     def forward(self, tokens):
-        dt = self.compute_dtype
+        dt = self.trunk_dtype
         table = engine.packed(self.token_embedding.weight, "emb", dt, lambda w: w.to(dt).contiguous())
         pos = engine.packed(self.position_embedding, "pos", dt, lambda w: w.to(dt).contiguous())
         return ops.clip_embed(tokens.to(torch.long).contiguous(), table, pos)
 
 
 class CLIPLayer(engine.HipModule):
+    f32_trunk = True
+
     def __init__(self, n_heads: int, n_embeddings: int, attention_type="xformers"):
         super().__init__()
         if attention_type not in _ATTENTION_TYPES:
@@ -35,15 +39,19 @@ class CLIPLayer(engine.HipModule):
         self.linear_2 = nn.Linear(n_embeddings * 4, n_embeddings)
 
     def run(self, x):
-        x = engine.self_attention(engine.layernorm(x, self.layernorm_1), self.attention, causal=True, residual=x)
-        h = engine.linear(engine.layernorm(x, self.layernorm_2), self.linear_1, act=ops.ACT_QUICK_GELU)
+        """x [B,77,768] in the trunk dtype."""
+        dt = self.compute_dtype
+        x = engine.self_attention(engine.layernorm(x, self.layernorm_1, dt), self.attention, causal=True, residual=x)
+        h = engine.linear(engine.layernorm(x, self.layernorm_2, dt), self.linear_1, act=ops.ACT_QUICK_GELU)
         return engine.linear(h, self.linear_2, residual=x)
 
     def forward(self, x):
-        return self.run(ops.cast(x.contiguous(), self.compute_dtype))
+        return self.run(ops.cast(x.contiguous(), self.trunk_dtype))
 
 
 class CLIP(engine.HipModule):
+    f32_trunk = True
+
     def __init__(self, attention_type="xformers"):
         super().__init__()
         self.embedding = CLIPEmbedding(49408, 768, 77)
@@ -55,4 +63,4 @@ class CLIP(engine.HipModule):
         state = self.embedding(tokens)
         for layer in self.layers:
             state = layer.run(state)
-        return engine.layernorm(state, self.layernorm)
+        return engine.layernorm(state, self.layernorm, self.compute_dtype)

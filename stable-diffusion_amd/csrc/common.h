@@ -62,6 +62,23 @@ template <> __device__ __forceinline__ void store_vec<bf16_t>(bf16_t* p, const f
   *reinterpret_cast<u32x4_t*>(p) = t;
 }
 
+// store V consecutive values as T (V = 4 or 8): one 8- or 16-byte vector store (two for 8 floats)
+template <typename T, int V> __device__ __forceinline__ void store_n(T* p, const float (&v)[V]) {
+  if constexpr (sizeof(T) == 4) {
+#pragma unroll
+    for (int k = 0; k < V / 4; ++k)
+      *reinterpret_cast<f32x4_t*>(p + 4 * k) = (f32x4_t){v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]};
+  } else if constexpr (V == 8) {
+    u32x4_t t;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) t[i] = pack_bf2(v[2 * i], v[2 * i + 1]);
+    *reinterpret_cast<u32x4_t*>(p) = t;
+  } else {
+    u32x2_t t = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+    *reinterpret_cast<u32x2_t*>(p) = t;
+  }
+}
+
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + expf(-x)); }
 __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float quick_gelu_f(float x) { return x / (1.0f + expf(-1.702f * x)); }

@@ -165,6 +165,25 @@ __global__ __launch_bounds__(256) void cast_kernel(const TI* __restrict__ src, T
     Cvt<TO>::st(dst + i, Cvt<TI>::ld(src + i));
 }
 
+// hi/lo split of an f32 matrix into two bf16 terms: dst [rows][2K] = [bf16(x) | bf16(x - bf16(x))].
+// A GEMM over the doubled K against [W | W] then sees the f32 operand to ~2^-17 (used where the
+// un-normalised residual trunk itself is a GEMM operand: 1x1 skip convs and conv_output).
+__global__ __launch_bounds__(256) void split_hilo_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, size_t rows,
+                                                         int K) {
+  const int vpr = K / 4;
+  const size_t total = rows * vpr;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const size_t r = i / vpr;
+    const int cv = (int)(i - r * vpr);
+    const f32x4_t x = *reinterpret_cast<const f32x4_t*>(src + r * K + (size_t)cv * 4);
+    float hi[4], lo[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { hi[j] = bf2f(f2bf(x[j])); lo[j] = x[j] - hi[j]; }
+    store_n<bf16_t, 4>(dst + r * 2 * K + (size_t)cv * 4, hi);
+    store_n<bf16_t, 4>(dst + r * 2 * K + K + (size_t)cv * 4, lo);
+  }
+}
+
 // y = silu(x), f32 (time-embedding path: diffusion.py:32)
 __global__ __launch_bounds__(256) void silu_kernel(const float* __restrict__ src, float* __restrict__ dst, size_t n) {
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] = silu_f(src[i]);
@@ -370,6 +389,13 @@ extern "C" int sdamd_cast(const void* src, void* dst, long long n, int src_dtype
   else if (src_dtype == SDAMD_F32 && dst_dtype == SDAMD_F32) cast_kernel<float, float><<<g, 256, 0, st>>>((const float*)src, (float*)dst, (size_t)n);
   else cast_kernel<bf16_t, bf16_t><<<g, 256, 0, st>>>((const bf16_t*)src, (bf16_t*)dst, (size_t)n);
   SD_LAUNCH_CHECK("cast");
+  return 0;
+}
+
+extern "C" int sdamd_split_hilo(const float* src, void* dst, long long rows, int K, void* stream) {
+  SD_CHECK(rows > 0 && K > 0 && K % 4 == 0, "split_hilo: bad shape rows=%lld K=%d", rows, K);
+  split_hilo_kernel<<<grid_for((size_t)rows * (K / 4)), 256, 0, (hipStream_t)stream>>>(src, (bf16_t*)dst, (size_t)rows, K);
+  SD_LAUNCH_CHECK("split_hilo");
   return 0;
 }
 

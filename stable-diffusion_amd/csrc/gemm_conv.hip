@@ -28,7 +28,7 @@ struct GemmArgs {
   const void* W;     // [N][ldw], K-contiguous (conv: [Cout][ky][kx][Cin])
   void* C;           // [M][ldc]
   const float* bias; // [N] or null
-  const void* R;     // residual [M][ldr] (same dtype as A) or null
+  const void* R;     // residual [M][ldr] (same dtype as C: f32 when out_f32, else the operand dtype) or null
   int M, N, K;
   int lda, ldw, ldc, ldr;
   long long sA, sW, sC, sR;  // batch strides (elements), grid.y = batch
@@ -175,7 +175,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
 
   // epilogue: lane holds out[m][n..n+3]
   const float* __restrict__ bias = p.bias;
-  const T* __restrict__ R = p.R ? (const T*)p.R + (size_t)batch * p.sR : nullptr;
+  const bool of32 = p.out_f32 || sizeof(T) == 4;
+  const T* __restrict__ R = (p.R && !of32) ? (const T*)p.R + (size_t)batch * p.sR : nullptr;
+  const float* __restrict__ Rf = (p.R && of32) ? (const float*)p.R + (size_t)batch * p.sR : nullptr;
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     const int m = m0 + wm * (BM / 2) + i * 16 + r16;
@@ -190,7 +192,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] += b[r];
       }
-      if (R) {
+      if (Rf) {
+        const f32x4_t rv = *reinterpret_cast<const f32x4_t*>(Rf + (size_t)m * p.ldr + n);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += rv[r];
+      } else if (R) {
         const T* rp = R + (size_t)m * p.ldr + n;
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] += Cvt<T>::ld(rp + r);
@@ -202,7 +208,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = silu_f(v[r]);
       }
-      if (p.out_f32 || sizeof(T) == 4) {
+      if (of32) {
         float* cp = (float*)p.C + (size_t)batch * p.sC + (size_t)m * p.ldc + n;
         *reinterpret_cast<f32x4_t*>(cp) = (f32x4_t){v[0], v[1], v[2], v[3]};
       } else {
@@ -397,7 +403,7 @@ extern "C" int sdamd_gemm(const void* A, const void* W, void* C, const float* bi
   const int esz = dtype == SDAMD_BF16 ? 2 : 4;
   SD_CHECK((lda * esz) % 16 == 0 && lda >= K && ldw >= K && ldc >= N, "gemm: bad leading dimensions lda=%d ldw=%d ldc=%d", lda, ldw, ldc);
   SD_CHECK(batch >= 1, "gemm: batch=%d", batch);
-  SD_CHECK(!residual || ldr >= N, "gemm: ldr=%d < N", ldr);
+  SD_CHECK(!residual || (ldr >= N && ldr % 4 == 0 && ((uintptr_t)residual % 16) == 0), "gemm: residual needs ldr=%d >= N, ldr %% 4 == 0 and 16-byte alignment", ldr);
   hipStream_t st = (hipStream_t)stream;
   if (dtype == SDAMD_BF16) return pick_tile<bf16_t, false>(a, batch, st);
   return pick_tile<float, false>(a, batch, st);

@@ -95,8 +95,8 @@ __global__ __launch_bounds__(64) void gn_finalize_kernel(const double* __restric
 }
 
 // GroupNorm apply (+ optional SiLU): grid (nblk2, B); pure streaming pass, 16-byte vectors.
-template <typename T>
-__global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, T* __restrict__ y,
+template <typename T, typename TO>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, TO* __restrict__ y,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        const float* __restrict__ fin, int HW, int C, int silu,
                                                        int pix_per_blk) {
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
       v[j] = silu ? silu_f(r) : r;
       if (++rem == cpg) { rem = 0; ++g; }
     }
-    store_vec<T>(y + off, v);
+    store_n<TO, V>(y + off, v);
     p += dp; cv += dcv;
     if (cv >= vpp) { cv -= vpp; ++p; }
   }
@@ -147,8 +147,8 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
 // LayerNorm over the last dim: one wave per row, the row lives in registers (C <= 64*5*V).
 // ---------------------------------------------------------------------------------------------
 constexpr int LN_MAXIT = 5;
-template <typename T>
-__global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x, T* __restrict__ y,
+template <typename T, typename TO>
+__global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x, TO* __restrict__ y,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         int rows, int C, float eps) {
   constexpr int V = 16 / sizeof(T);
@@ -179,18 +179,20 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x,
     }
   }
   const float rstd = 1.0f / sqrtf(wave_sum(sq) / (float)C + eps);
-  T* yr = y + (size_t)row * C;
+  TO* yr = y + (size_t)row * C;
 #pragma unroll
   for (int i = 0; i < LN_MAXIT; ++i) {
     int cv = lane + i * 64;
     if (cv < nvec) {
       float o[V];
 #pragma unroll
-      for (int j = 0; j < V; ++j) {
-        int c = cv * V + j;
-        o[j] = (v[i][j] - mean) * rstd * gamma[c] + beta[c];
+      for (int k = 0; k < V / 4; ++k) {
+        const f32x4_t gm = *reinterpret_cast<const f32x4_t*>(gamma + cv * V + 4 * k);
+        const f32x4_t bt = *reinterpret_cast<const f32x4_t*>(beta + cv * V + 4 * k);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[4 * k + j] = (v[i][4 * k + j] - mean) * rstd * gm[j] + bt[j];
       }
-      store_vec<T>(yr + (size_t)cv * V, o);
+      store_n<TO, V>(yr + (size_t)cv * V, o);
     }
   }
 }
@@ -240,8 +242,10 @@ static int gn_geometry(int C, int V, int* tpp, int* nchunk) {
 extern "C" size_t sdamd_groupnorm_ws_bytes(int B) { return (size_t)B * (64 * 32 * 2 * sizeof(double) + 32 * 2 * sizeof(float)); }
 
 extern "C" int sdamd_groupnorm_nhwc(const void* x, void* y, const float* gamma, const float* beta, void* ws, int B,
-                                    int HW, int C, float eps, int silu, int dtype, void* stream) {
+                                    int HW, int C, float eps, int silu, int dtype, int out_dtype, void* stream) {
   const int V = dtype == SDAMD_BF16 ? 8 : 4;
+  SD_CHECK((dtype == SDAMD_BF16 || dtype == SDAMD_F32) && (out_dtype == SDAMD_BF16 || out_dtype == SDAMD_F32) &&
+           !(dtype == SDAMD_BF16 && out_dtype == SDAMD_F32), "groupnorm: unsupported dtypes in=%d out=%d", dtype, out_dtype);
   SD_CHECK(C % 32 == 0 && C % V == 0, "groupnorm: C=%d must be a multiple of 32 and of the 16-byte vector", C);
   SD_CHECK(B > 0 && HW > 0, "groupnorm: empty input B=%d HW=%d", B, HW);
   int tpp, nchunk;
@@ -280,24 +284,30 @@ extern "C" int sdamd_groupnorm_nhwc(const void* x, void* y, const float* gamma, 
   int nblk2 = (HW + ppb2 - 1) / ppb2;
   dim3 grid2(nblk2, B);
   if (dtype == SDAMD_BF16)
-    gn_apply_kernel<bf16_t><<<grid2, 256, 0, st>>>((const bf16_t*)x, (bf16_t*)y, gamma, beta, fin, HW, C, silu, ppb2);
+    gn_apply_kernel<bf16_t, bf16_t><<<grid2, 256, 0, st>>>((const bf16_t*)x, (bf16_t*)y, gamma, beta, fin, HW, C, silu, ppb2);
+  else if (out_dtype == SDAMD_BF16)
+    gn_apply_kernel<float, bf16_t><<<grid2, 256, 0, st>>>((const float*)x, (bf16_t*)y, gamma, beta, fin, HW, C, silu, ppb2);
   else
-    gn_apply_kernel<float><<<grid2, 256, 0, st>>>((const float*)x, (float*)y, gamma, beta, fin, HW, C, silu, ppb2);
+    gn_apply_kernel<float, float><<<grid2, 256, 0, st>>>((const float*)x, (float*)y, gamma, beta, fin, HW, C, silu, ppb2);
   SD_LAUNCH_CHECK("gn_apply");
   return 0;
 }
 
 extern "C" int sdamd_layernorm(const void* x, void* y, const float* gamma, const float* beta, int rows, int C, float eps,
-                               int dtype, void* stream) {
+                               int dtype, int out_dtype, void* stream) {
   const int V = dtype == SDAMD_BF16 ? 8 : 4;
+  SD_CHECK((dtype == SDAMD_BF16 || dtype == SDAMD_F32) && (out_dtype == SDAMD_BF16 || out_dtype == SDAMD_F32) &&
+           !(dtype == SDAMD_BF16 && out_dtype == SDAMD_F32), "layernorm: unsupported dtypes in=%d out=%d", dtype, out_dtype);
   SD_CHECK(C % V == 0 && C / V <= 64 * LN_MAXIT, "layernorm: unsupported C=%d", C);
   SD_CHECK(rows > 0, "layernorm: empty input");
   hipStream_t st = (hipStream_t)stream;
   int grid = (rows + 3) / 4;
   if (dtype == SDAMD_BF16)
-    layernorm_kernel<bf16_t><<<grid, 256, 0, st>>>((const bf16_t*)x, (bf16_t*)y, gamma, beta, rows, C, eps);
+    layernorm_kernel<bf16_t, bf16_t><<<grid, 256, 0, st>>>((const bf16_t*)x, (bf16_t*)y, gamma, beta, rows, C, eps);
+  else if (out_dtype == SDAMD_BF16)
+    layernorm_kernel<float, bf16_t><<<grid, 256, 0, st>>>((const float*)x, (bf16_t*)y, gamma, beta, rows, C, eps);
   else
-    layernorm_kernel<float><<<grid, 256, 0, st>>>((const float*)x, (float*)y, gamma, beta, rows, C, eps);
+    layernorm_kernel<float, float><<<grid, 256, 0, st>>>((const float*)x, (float*)y, gamma, beta, rows, C, eps);
   SD_LAUNCH_CHECK("layernorm");
   return 0;
 }

@@ -14,6 +14,8 @@ from .attention import SelfAttention
 
 
 class VAE_ResidualBlock(engine.HipModule):
+    f32_trunk = True
+
     def __init__(self, input_channel, output_channel):
         super().__init__()
         self.groupnorm_1 = nn.GroupNorm(32, input_channel)
@@ -24,16 +26,21 @@ class VAE_ResidualBlock(engine.HipModule):
                                else nn.Conv2d(input_channel, output_channel, kernel_size=1, padding=0))
 
     def run(self, x):
-        h = engine.conv3x3(engine.groupnorm(x, self.groupnorm_1, silu=True), self.conv_1)
+        """x NHWC in the trunk dtype (f32 trunk / compute-dtype operands, as in the UNet blocks)."""
+        dt = self.compute_dtype
+        h = engine.conv3x3(engine.groupnorm(x, self.groupnorm_1, silu=True, out_dtype=dt), self.conv_1)
         h = engine.groupnorm(h, self.groupnorm_2, silu=True)
-        skip = x if isinstance(self.residual_layer, nn.Identity) else engine.conv1x1(x, self.residual_layer)
+        skip = x if isinstance(self.residual_layer, nn.Identity) else \
+            engine.conv1x1(ops.cast(x, dt), self.residual_layer, out_dtype=x.dtype)
         return engine.conv3x3(h, self.conv_2, residual=skip)
 
     def forward(self, x):
-        return ops.nhwc_to_nchw(self.run(ops.nchw_to_nhwc(x, self.compute_dtype)))
+        return ops.nhwc_to_nchw(self.run(ops.nchw_to_nhwc(x, self.trunk_dtype)))
 
 
 class VAE_AttentionBlock(engine.HipModule):
+    f32_trunk = True
+
     def __init__(self, channels):
         super().__init__()
         self.groupnorm = nn.GroupNorm(32, channels)
@@ -41,16 +48,17 @@ class VAE_AttentionBlock(engine.HipModule):
 
     def run(self, x):
         B, H, W, C = x.shape
-        t = engine.groupnorm(x, self.groupnorm, silu=False).view(B, H * W, C)
+        t = engine.groupnorm(x, self.groupnorm, silu=False, out_dtype=self.compute_dtype).view(B, H * W, C)
         return engine.self_attention(t, self.attention, residual=x.view(B, H * W, C)).view(B, H, W, C)
 
     def forward(self, x):
-        return ops.nhwc_to_nchw(self.run(ops.nchw_to_nhwc(x, self.compute_dtype)))
+        return ops.nhwc_to_nchw(self.run(ops.nchw_to_nhwc(x, self.trunk_dtype)))
 
 
-def run_vae_stack(modules, x):
-    """Drive decoder/encoder members on an NHWC tensor; returns (x, index of the first member
-    not consumed) so the callers can finish with their own epilogue."""
+def run_vae_stack(modules, x, compute_dtype):
+    """Drive decoder/encoder members on an NHWC trunk tensor.  The plain convs between blocks take
+    the trunk as operand: it is rounded to the compute dtype for them (no CFG after the VAE, so the
+    two-term split the UNet uses there is not worth its FLOPs)."""
     pending_up = False
     for m in modules:
         if isinstance(m, (VAE_ResidualBlock, VAE_AttentionBlock)):
@@ -59,9 +67,9 @@ def run_vae_stack(modules, x):
             pending_up = True
         elif isinstance(m, nn.Conv2d):
             if m.stride == (2, 2):   # encoder: F.pad(0,1,0,1) + stride-2 conv (encoder.py:65-66)
-                x = engine.conv3x3(x, m, stride=2, pad_mode=1)
+                x = engine.conv3x3(ops.cast(x, compute_dtype), m, stride=2, pad_mode=1, out_dtype=x.dtype)
             else:
-                x = engine.conv3x3(x, m, upsample=pending_up)
+                x = engine.conv3x3(ops.cast(x, compute_dtype), m, upsample=pending_up, out_dtype=x.dtype)
             pending_up = False
         else:
             raise TypeError(type(m))
@@ -69,6 +77,8 @@ def run_vae_stack(modules, x):
 
 
 class VAE_Decoder(nn.Sequential, engine.HipModule):
+    f32_trunk = True
+
     def __init__(self):
         r = VAE_ResidualBlock
         super().__init__(
@@ -89,8 +99,8 @@ class VAE_Decoder(nn.Sequential, engine.HipModule):
         dt = self.compute_dtype
         mods = list(self)
         pq = ops.vae_post_quant(x.float().contiguous(), engine.f32(mods[0].weight), engine.f32(mods[0].bias))
-        h = ops.conv3x3_cin_small(pq, engine.conv3x3_cin_small_w(mods[1]), engine.f32(mods[1].bias), dt)
-        h = run_vae_stack(mods[2:23], h)
-        h = engine.groupnorm(h, mods[23], silu=True)
+        h = ops.conv3x3_cin_small(pq, engine.conv3x3_cin_small_w(mods[1]), engine.f32(mods[1].bias), self.trunk_dtype)
+        h = run_vae_stack(mods[2:23], h, dt)
+        h = engine.groupnorm(h, mods[23], silu=True, out_dtype=dt)
         last = mods[25]
         return ops.conv3x3_cout_small(h, engine.conv3x3_cout_small_w(last, dt), engine.f32(last.bias), 3)

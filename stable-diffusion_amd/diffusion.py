@@ -23,6 +23,8 @@ _ATTENTION_TYPES = ("xformers", "flashattention", "default")  # all map to the o
 
 
 class UNET_ResidualBlock(engine.HipModule):
+    f32_trunk = True
+
     def __init__(self, input_channel: int, output_channel: int, n_time=1280):
         super().__init__()
         self.groupnorm_feature = nn.GroupNorm(32, input_channel)
@@ -40,20 +42,23 @@ class UNET_ResidualBlock(engine.HipModule):
         return ops.gemm(time_silu, w, b).reshape(-1)
 
     def run(self, x, tbias):
-        """x NHWC; tbias f32 [Cout]."""
-        h = engine.groupnorm(x, self.groupnorm_feature, silu=True)
+        """x NHWC in the trunk dtype; tbias f32 [Cout].  Operands of the convs are compute dtype."""
+        dt = self.compute_dtype
+        h = engine.groupnorm(x, self.groupnorm_feature, silu=True, out_dtype=dt)
         h = engine.conv3x3(h, self.conv_feature, bias=tbias)
         h = engine.groupnorm(h, self.groupnorm_merged, silu=True)
-        skip = x if isinstance(self.residual_layer, nn.Identity) else engine.conv1x1(x, self.residual_layer)
+        skip = x if isinstance(self.residual_layer, nn.Identity) else \
+            engine.conv1x1(x, self.residual_layer, out_dtype=x.dtype, compute_dtype=dt)
         return engine.conv3x3(h, self.conv_merged, residual=skip)
 
     def forward(self, feature, time):
-        dt = self.compute_dtype
         tb = self.time_bias(ops.silu(time.float().contiguous()))
-        return ops.nhwc_to_nchw(self.run(ops.nchw_to_nhwc(feature, dt), tb))
+        return ops.nhwc_to_nchw(self.run(ops.nchw_to_nhwc(feature, self.trunk_dtype), tb))
 
 
 class UNET_AttentionBlock(engine.HipModule):
+    f32_trunk = True
+
     def __init__(self, n_heads: int, n_embeddings: int, d_prompt=768, attention_type="xformers"):
         super().__init__()
         if attention_type not in _ATTENTION_TYPES:
@@ -71,34 +76,41 @@ class UNET_AttentionBlock(engine.HipModule):
         self.conv_output = nn.Conv2d(channels, channels, kernel_size=1, padding=0)
 
     def prompt_kv(self, ctx):
-        return engine.cross_kv(ctx, self.attention_2)
+        """K|V projection of the prompt, computed in the context's own dtype (f32 context from an
+        f32 text encoder stays f32 through this once-per-prompt GEMM), stored as MFMA operands."""
+        return ops.cast(engine.cross_kv(ctx, self.attention_2), self.compute_dtype)
 
     def run(self, x, kv):
-        """x NHWC [B,h,w,C]; kv = self.prompt_kv(context) [B,77,2C]."""
+        """x NHWC [B,h,w,C] in the trunk dtype; kv = self.prompt_kv(context) [B,77,2C].  The token
+        stream ``t`` is a trunk too (three residual adds accumulate into it)."""
         B, H, W, C = x.shape
-        t = engine.conv1x1(engine.groupnorm(x, self.groupnorm, silu=False), self.conv_input).view(B, H * W, C)
-        t = engine.self_attention(engine.layernorm(t, self.layernorm_1), self.attention_1, residual=t)
-        t = engine.cross_attention(engine.layernorm(t, self.layernorm_2), self.attention_2, kv, residual=t)
-        g = ops.geglu(engine.linear(engine.layernorm(t, self.layernorm_3), self.linear_geglu_1))
+        dt, td = self.compute_dtype, x.dtype
+        t = engine.conv1x1(engine.groupnorm(x, self.groupnorm, silu=False, out_dtype=dt), self.conv_input,
+                           out_dtype=td).view(B, H * W, C)
+        t = engine.self_attention(engine.layernorm(t, self.layernorm_1, dt), self.attention_1, residual=t)
+        t = engine.cross_attention(engine.layernorm(t, self.layernorm_2, dt), self.attention_2, kv, residual=t)
+        g = ops.geglu(engine.linear(engine.layernorm(t, self.layernorm_3, dt), self.linear_geglu_1))
         t = engine.linear(g, self.linear_geglu_2, residual=t)
-        return engine.conv1x1(t.view(B, H, W, C), self.conv_output, residual=x)
+        return engine.conv1x1(t.view(B, H, W, C), self.conv_output, residual=x, compute_dtype=dt)
 
     def forward(self, x, prompt):
-        dt = self.compute_dtype
-        kv = self.prompt_kv(ops.cast(prompt.contiguous(), dt))
-        return ops.nhwc_to_nchw(self.run(ops.nchw_to_nhwc(x, dt), kv))
+        kv = self.prompt_kv(prompt.contiguous())
+        return ops.nhwc_to_nchw(self.run(ops.nchw_to_nhwc(x, self.trunk_dtype), kv))
 
 
 class Upsample(engine.HipModule):
+    f32_trunk = True
+
     def __init__(self, channels):
         super().__init__()
         self.conv = nn.Conv2d(channels, channels, kernel_size=3, padding=1)
 
     def run(self, x):
-        return engine.conv3x3(x, self.conv, upsample=True)  # nearest-2x folded into the conv's gather
+        # nearest-2x folded into the conv's gather; trunk in, trunk out
+        return engine.conv3x3_trunk(x, self.conv, self.compute_dtype, upsample=True)
 
     def forward(self, x):
-        return ops.nhwc_to_nchw(self.run(ops.nchw_to_nhwc(x, self.compute_dtype)))
+        return ops.nhwc_to_nchw(self.run(ops.nchw_to_nhwc(x, self.trunk_dtype)))
 
 
 class TimeEmbedding(engine.HipModule):
@@ -130,6 +142,8 @@ def _res_attn(cin, cout, d_head, at):
 
 
 class UNET(engine.HipModule):
+    f32_trunk = True
+
     def __init__(self, attention_type="xformers"):
         super().__init__()
         if attention_type not in _ATTENTION_TYPES:
@@ -161,6 +175,7 @@ class UNET(engine.HipModule):
 
     def prompt_state(self, ctx):
         """K|V projections of the prompt for all 16 attention blocks (constant over the loop)."""
+        ctx = ctx.contiguous()
         return {id(a): a.prompt_kv(ctx) for a in self.attention_blocks()}
 
     def time_bias_table(self, time):
@@ -184,8 +199,8 @@ class UNET(engine.HipModule):
         return out
 
     def run(self, x_nchw, kv, tbias):
-        """x_nchw f32 [B,4,h,w] -> NHWC [B,h,w,320] in compute dtype."""
-        dt = self.compute_dtype
+        """x_nchw f32 [B,4,h,w] -> NHWC [B,h,w,320] in the trunk dtype."""
+        dt = self.trunk_dtype
         skips = []
         x = None
         for i, stage in enumerate(self.encoders):
@@ -200,8 +215,7 @@ class UNET(engine.HipModule):
             x = self._stage(stage, ops.concat_channels(x, skips.pop()), kv, tbias)
         return x
 
-    @staticmethod
-    def _stage(stage, x, kv, tbias):
+    def _stage(self, stage, x, kv, tbias):
         for m in stage:
             if isinstance(m, UNET_ResidualBlock):
                 x = m.run(x, tbias[id(m)])
@@ -209,35 +223,41 @@ class UNET(engine.HipModule):
                 x = m.run(x, kv[id(m)])
             elif isinstance(m, Upsample):
                 x = m.run(x)
-            else:  # stride-2 downsampling conv
-                x = engine.conv3x3(x, m, stride=2)
+            else:  # stride-2 downsampling conv: trunk in, trunk out
+                x = engine.conv3x3_trunk(x, m, self.compute_dtype, stride=2)
         return x
 
     def forward(self, x, prompt, time):
         """x [B,4,h,w], prompt [B,77,768], time [1,1280] -> [B,320,h,w] (diffusion.py:264-281)."""
         dt = self.compute_dtype
-        kv = self.prompt_state(ops.cast(prompt.contiguous(), dt))
+        kv = self.prompt_state(prompt)
         tb = self.time_bias_slices(self.time_bias_table(time).reshape(-1))
         return ops.nhwc_to_nchw(self.run(x.float().contiguous(), kv, tb))
 
 
 class UNET_Output_Layer(engine.HipModule):
+    f32_trunk = True
+
     def __init__(self, input_channel, output_channel):
         super().__init__()
         self.groupnorm = nn.GroupNorm(32, input_channel)
         self.conv = nn.Conv2d(input_channel, output_channel, kernel_size=3, padding=1)
 
     def run(self, x):
-        """NHWC [B,h,w,320] -> NCHW f32 [B,4,h,w]."""
+        """NHWC [B,h,w,320] (trunk dtype) -> NCHW f32 [B,4,h,w].  Stays in the trunk dtype: nothing
+        dilutes this layer's rounding (its output IS eps, which CFG then amplifies), and it is
+        0.006 % of the UNet's FLOPs."""
         h = engine.groupnorm(x, self.groupnorm, silu=True)
         return ops.conv3x3_cout_small(h, engine.conv3x3_cout_small_w(self.conv, h.dtype), engine.f32(self.conv.bias),
                                       self.conv.out_channels)
 
     def forward(self, x):
-        return self.run(ops.nchw_to_nhwc(x, self.compute_dtype))
+        return self.run(ops.nchw_to_nhwc(x, self.trunk_dtype))
 
 
 class Diffusion(engine.HipModule):
+    f32_trunk = True
+
     def __init__(self, attention_type="xformers"):
         super().__init__()
         self.time_embedding = TimeEmbedding(320)
@@ -251,6 +271,6 @@ class Diffusion(engine.HipModule):
     def forward(self, latent, prompt, time):
         """latent [B,4,h,w], prompt [B,77,768], time [1,320] -> [B,4,h,w] f32 (diffusion.py:309-324)."""
         dt = self.compute_dtype
-        kv = self.unet.prompt_state(ops.cast(prompt.contiguous(), dt))
+        kv = self.unet.prompt_state(prompt)
         table = self.unet.time_bias_table(self.time_embedding(time))
         return self.run(latent.float().contiguous(), kv, self.unet.time_bias_slices(table.reshape(-1)))

@@ -9,6 +9,8 @@ from .decoder import VAE_AttentionBlock, VAE_ResidualBlock, run_vae_stack
 
 
 class VAE_Encoder(nn.Sequential, engine.HipModule):
+    f32_trunk = True
+
     def __init__(self):
         r = VAE_ResidualBlock
         super().__init__(
@@ -31,8 +33,9 @@ class VAE_Encoder(nn.Sequential, engine.HipModule):
         """x [B,3,H,W] f32 in (-1,1), noise [B,4,H/8,W/8] -> latents [B,4,H/8,W/8] f32."""
         dt = self.compute_dtype
         mods = list(self)
-        h = ops.conv3x3_cin_small(x.float().contiguous(), engine.conv3x3_cin_small_w(mods[0]), engine.f32(mods[0].bias), dt)
-        h = run_vae_stack(mods[1:15], h)
-        h = engine.groupnorm(h, mods[15], silu=True)
+        h = ops.conv3x3_cin_small(x.float().contiguous(), engine.conv3x3_cin_small_w(mods[0]), engine.f32(mods[0].bias),
+                                  self.trunk_dtype)
+        h = run_vae_stack(mods[1:15], h, dt)
+        h = engine.groupnorm(h, mods[15], silu=True, out_dtype=dt)
         moments = ops.conv3x3_cout_small(h, engine.conv3x3_cout_small_w(mods[17], dt), engine.f32(mods[17].bias), 8)
         return ops.vae_sample(moments, noise.float().contiguous(), engine.f32(mods[18].weight), engine.f32(mods[18].bias))

@@ -38,10 +38,21 @@ def clear_cache():
 
 
 class HipModule(nn.Module):
-    """Base of every module that executes through libsdamd.  ``compute_dtype`` is the storage
-    type of activations and weights on the device (float32 or bfloat16)."""
+    """Base of every module that executes through libsdamd.  ``compute_dtype`` is the type of the
+    MFMA operands (weights and normalised activations) on the device: float32 or bfloat16.
+
+    ``f32_trunk`` (class attribute): when the compute dtype is bfloat16, keep the residual stream
+    ("trunk": every tensor that a residual add accumulates into) in float32.  GroupNorm /
+    LayerNorm read the f32 trunk and emit bf16 operands, GEMM/conv epilogues add the f32 residual
+    and write f32.  The UNet and CLIP need it: classifier-free guidance amplifies the UNet's
+    rounding noise ~10x (measured: pure bf16 3.6e-2 on eps, this scheme 1.7e-2; experiments/)."""
 
     compute_dtype = torch.float32
+    f32_trunk = False
+
+    @property
+    def trunk_dtype(self):
+        return torch.float32 if self.f32_trunk else self.compute_dtype
 
 
 def set_compute_dtype(module, dtype):
@@ -93,31 +104,58 @@ def conv3x3_cout_small_w(conv, dtype):
 
 
 # ---- shared blocks ---------------------------------------------------------------------------
-def linear(x, lin, residual=None, act=ops.ACT_NONE, out_f32=False):
-    return ops.gemm(x, linear_w(lin, x.dtype), bias_of(lin), residual, act, out_f32)
+# Dtype rule of every GEMM-like helper: the operand ``x`` has the compute dtype; the result has
+# ``out_dtype`` (default: the residual's dtype if there is one, else x's); a residual has the
+# result's dtype.
+def _out_f32(x, residual, out_dtype):
+    if out_dtype is None:
+        out_dtype = x.dtype if residual is None else residual.dtype
+    return out_dtype == torch.float32 and x.dtype != torch.float32
 
 
-def conv1x1(x, conv, residual=None):
-    """x NHWC [B,H,W,C]."""
-    return ops.gemm(x, conv1x1_w(conv, x.dtype), bias_of(conv), residual)
+def linear(x, lin, residual=None, act=ops.ACT_NONE, out_dtype=None):
+    return ops.gemm(x, linear_w(lin, x.dtype), bias_of(lin), residual, act, _out_f32(x, residual, out_dtype))
 
 
-def conv3x3(x, conv, residual=None, stride=1, pad_mode=0, upsample=False, bias=None):
+def conv1x1(x, conv, residual=None, out_dtype=None, compute_dtype=None):
+    """x NHWC [B,H,W,C].  An f32 ``x`` under a bf16 compute dtype is the residual trunk itself:
+    it goes through the MFMA as two bf16 terms (hi|lo) against [W|W] instead of being rounded."""
+    if compute_dtype == torch.bfloat16 and x.dtype == torch.float32:
+        w2 = packed(conv.weight, "c1x2", torch.bfloat16,
+                    lambda w: w.reshape(w.shape[0], w.shape[1]).to(torch.bfloat16).repeat(1, 2).contiguous())
+        xs = ops.split_hilo(x)
+        return ops.gemm(xs, w2, bias_of(conv), residual, ops.ACT_NONE, _out_f32(xs, residual, out_dtype))
+    return ops.gemm(x, conv1x1_w(conv, x.dtype), bias_of(conv), residual, ops.ACT_NONE, _out_f32(x, residual, out_dtype))
+
+
+def conv3x3(x, conv, residual=None, stride=1, pad_mode=0, upsample=False, bias=None, out_dtype=None):
     return ops.conv3x3(x, conv3x3_w(conv, x.dtype), bias_of(conv) if bias is None else bias, residual, stride,
-                       pad_mode, upsample)
+                       pad_mode, upsample, out_f32=_out_f32(x, residual, out_dtype))
 
 
-def groupnorm(x, gn, silu):
-    return ops.groupnorm(x, f32(gn.weight), f32(gn.bias), gn.eps, silu)
+def conv3x3_trunk(x, conv, compute_dtype, stride=1, upsample=False):
+    """conv3x3 whose operand is the residual trunk itself (UNet down/upsampling convs): result in
+    x's dtype; an f32 trunk under bf16 compute goes through the MFMA as [hi|lo] channels against
+    [W|W] per tap (see conv1x1)."""
+    if compute_dtype == torch.bfloat16 and x.dtype == torch.float32:
+        w2 = packed(conv.weight, "c3x2", torch.bfloat16,
+                    lambda w: w.permute(0, 2, 3, 1).to(torch.bfloat16).repeat(1, 1, 1, 2).reshape(w.shape[0], -1).contiguous())
+        return ops.conv3x3(ops.split_hilo(x), w2, bias_of(conv), None, stride, 0, upsample, out_f32=True)
+    return ops.conv3x3(x, conv3x3_w(conv, x.dtype), bias_of(conv), None, stride, 0, upsample)
 
 
-def layernorm(x, ln):
-    return ops.layernorm(x, f32(ln.weight), f32(ln.bias), ln.eps)
+def groupnorm(x, gn, silu, out_dtype=None):
+    return ops.groupnorm(x, f32(gn.weight), f32(gn.bias), gn.eps, silu, out_dtype)
+
+
+def layernorm(x, ln, out_dtype=None):
+    return ops.layernorm(x, f32(ln.weight), f32(ln.bias), ln.eps, out_dtype)
 
 
 def self_attention(x, attn, causal=False, residual=None):
     """attention.py:25-75 on token-major x [B,S,C]: fused QKV GEMM -> flash attention (or the
-    GEMM/softmax/GEMM form for the 512-wide single VAE head) -> out-proj GEMM (+ residual)."""
+    GEMM/softmax/GEMM form for the 512-wide single VAE head) -> out-proj GEMM (+ residual, whose
+    dtype the result takes)."""
     qkv = linear(x, attn.in_proj)
     C = x.shape[-1]
     q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]

@@ -141,30 +141,32 @@ def gather_row(dst, table, step=0, step_ptr=None):
 
 
 # ------------------------------------------------------------------ norms
-def groupnorm(x, gamma, beta, eps, silu):
-    """x [B, ..., C] NHWC; 32 groups."""
+def groupnorm(x, gamma, beta, eps, silu, out_dtype=None):
+    """x [B, ..., C] NHWC; 32 groups.  ``out_dtype`` (default: x's) may be bfloat16 for f32 input."""
     _dev(x, gamma, beta)
     assert x.is_contiguous() and gamma.dtype == torch.float32 and beta.dtype == torch.float32
     B, C = x.shape[0], x.shape[-1]
     HW = x.numel() // (B * C)
     assert gamma.numel() == C and beta.numel() == C
-    y = torch.empty_like(x)
+    out_dtype = x.dtype if out_dtype is None else out_dtype
+    y = torch.empty(x.shape, dtype=out_dtype, device=x.device)
     ws = _groupnorm_ws(B, x.device)
-    _timed(f"groupnorm_{_dt(x.dtype)}", 3 * x.numel() * x.element_size(),   # stats read + apply read + write
+    _timed(f"groupnorm_{_dt(x.dtype)}", x.numel() * (2 * x.element_size() + y.element_size()),   # stats read + apply read + write
            lambda: _lib.check(_lib.lib().sdamd_groupnorm_nhwc(_p(x), _p(y), _p(gamma), _p(beta), _p(ws), B, HW, C, float(eps),
-                                                              int(silu), _code(x.dtype), _stream())))
+                                                              int(silu), _code(x.dtype), _code(out_dtype), _stream())))
     return y
 
 
-def layernorm(x, gamma, beta, eps=1e-5):
+def layernorm(x, gamma, beta, eps=1e-5, out_dtype=None):
     _dev(x, gamma, beta)
     assert x.is_contiguous() and gamma.dtype == torch.float32 and beta.dtype == torch.float32
     C = x.shape[-1]
     assert gamma.numel() == C and beta.numel() == C
-    y = torch.empty_like(x)
-    _timed(f"layernorm_{_dt(x.dtype)}", 2 * x.numel() * x.element_size(),
+    out_dtype = x.dtype if out_dtype is None else out_dtype
+    y = torch.empty(x.shape, dtype=out_dtype, device=x.device)
+    _timed(f"layernorm_{_dt(x.dtype)}", x.numel() * (x.element_size() + y.element_size()),
            lambda: _lib.check(_lib.lib().sdamd_layernorm(_p(x), _p(y), _p(gamma), _p(beta), x.numel() // C, C, float(eps),
-                                                         _code(x.dtype), _stream())))
+                                                         _code(x.dtype), _code(out_dtype), _stream())))
     return y
 
 
@@ -250,6 +252,17 @@ def cast(x, dtype):
     return out
 
 
+def split_hilo(x):
+    """f32 [..., K] -> bf16 [..., 2K] = [bf16(x) | bf16(x - bf16(x))] (pair with weights [W | W])."""
+    _dev(x)
+    assert x.dtype == torch.float32 and x.is_contiguous()
+    K = x.shape[-1]
+    out = torch.empty(x.shape[:-1] + (2 * K,), dtype=torch.bfloat16, device=x.device)
+    _timed("split_hilo", x.numel() * 8,
+           lambda: _lib.check(_lib.lib().sdamd_split_hilo(_p(x), _p(out), x.numel() // K, K, _stream())))
+    return out
+
+
 def silu(x):
     _dev(x)
     assert x.dtype == torch.float32 and x.is_contiguous()
@@ -312,7 +325,8 @@ def vae_sample(moments, noise, w, b):
 
 # ------------------------------------------------------------------ MFMA GEMM / conv / attention
 def gemm(a, w, bias=None, residual=None, act=ACT_NONE, out_f32=False):
-    """a [..., K] (last dim contiguous, uniform row stride), w [N, K] -> [..., N]."""
+    """a [..., K] (last dim contiguous, uniform row stride), w [N, K] -> [..., N].  The result (and the
+    residual, which must have the result's dtype) is f32 when ``out_f32``, else a's dtype."""
     _dev(a, w, bias, residual)
     K = a.shape[-1]
     N = w.shape[0]
@@ -331,7 +345,8 @@ def gemm(a, w, bias=None, residual=None, act=ACT_NONE, out_f32=False):
     out = torch.empty(lead + (N,), dtype=out_dtype, device=a.device)
     ldr = 0
     if residual is not None:
-        assert residual.dtype == a.dtype and residual.is_contiguous() and residual.numel() == M * N
+        assert residual.dtype == out_dtype and residual.is_contiguous() and residual.numel() == M * N, \
+            (residual.dtype, out_dtype, residual.shape, M, N)
         ldr = N
     if bias is not None:
         assert bias.dtype == torch.float32 and bias.numel() == N and bias.is_contiguous()
@@ -368,7 +383,7 @@ def conv3x3(x, w, bias, residual=None, stride=1, pad_mode=0, upsample=False, act
         Ho, Wo = (Hin + 1 - 3) // stride + 1, (Win + 1 - 3) // stride + 1
     out = torch.empty((B, Ho, Wo, Cout), dtype=torch.float32 if out_f32 else x.dtype, device=x.device)
     if residual is not None:
-        assert residual.shape == out.shape and residual.dtype == x.dtype and residual.is_contiguous()
+        assert residual.shape == out.shape and residual.dtype == out.dtype and residual.is_contiguous()
     if bias is not None:
         assert bias.dtype == torch.float32 and bias.numel() == Cout
     M = B * Ho * Wo

@@ -198,8 +198,8 @@ def test_denoise_steps_teacher_forced(models, dtype):
     """Each step fed the REFERENCE's previous latents (and the host noise stream): one UNet forward +
     CFG + DDPM step per comparison, no error carried between steps."""
     g = golden("pipeline_txt2img_3step")
-    for m in models.values():
-        with_dtype(m, dtype)
+    for name, m in models.items():
+        with_dtype(m, FP32 if name == "clip" else dtype)      # as pipeline.generate does
     tok = synth.SyntheticTokenizer()
     pos = pipeline._token_tensor(tok, ["synthetic:0"], DEV)
     neg = pipeline._token_tensor(tok, [""], DEV)

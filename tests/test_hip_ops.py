@@ -136,6 +136,38 @@ def test_layernorm(dtype, rows, C):
     assert rel_l2(got, want) < tol(dtype, 2e-6, 6e-3)
 
 
+def test_norms_f32_trunk_to_bf16_operand():
+    """f32 input, bf16 output (the f32-trunk form): only the result is rounded."""
+    for C, H, silu in ((320, 16, True), (1280, 8, False), (2560, 4, True)):
+        x = rnd(f"gnmix.{C}", (2, C, H, H), 2.0) + 0.5
+        gamma, beta = rnd(f"gn.g.{C}", (C,), 0.2) + 1.0, rnd(f"gn.b.{C}", (C,), 0.2)
+        want = F.group_norm(x, 32, gamma, beta, 1e-5)
+        want = F.silu(want) if silu else want
+        got = ops.groupnorm(to_nhwc(x, torch.float32), gamma.to(DEV), beta.to(DEV), 1e-5, silu, torch.bfloat16)
+        assert got.dtype == torch.bfloat16 and rel_l2(from_nhwc(got), want) < 3e-3
+    for rows, C in ((77, 768), (200, 1280), (64, 320)):
+        x = rnd(f"lnmix.{C}", (rows, C), 2.0) + 0.3
+        gamma, beta = rnd(f"ln.g.{C}", (C,), 0.2) + 1.0, rnd(f"ln.b.{C}", (C,), 0.2)
+        got = ops.layernorm(x.to(DEV), gamma.to(DEV), beta.to(DEV), 1e-5, torch.bfloat16)
+        assert got.dtype == torch.bfloat16 and rel_l2(got.float().cpu(), F.layer_norm(x, (C,), gamma, beta, 1e-5)) < 3e-3
+
+
+def test_split_hilo_gemm_keeps_f32_operand():
+    """[hi | lo] bf16 split of an f32 operand against [W | W]: operand error ~2^-17 instead of 2^-9."""
+    M, K, N = 300, 640, 320
+    a = rnd("split.a", (M, K), 3.0)
+    w = q(rnd("split.w", (N, K), 1.0 / math.sqrt(K)), torch.bfloat16)
+    r = rnd("split.r", (M, N))
+    xs = ops.split_hilo(a.to(DEV))
+    hi = a.bfloat16()
+    assert torch.equal(xs[:, :K].cpu(), hi) and torch.equal(xs[:, K:].cpu(), (a - hi.float()).bfloat16())
+    got = ops.gemm(xs, w.bfloat16().repeat(1, 2).contiguous().to(DEV), None, r.to(DEV), out_f32=True)
+    want = (a.double() @ w.double().t() + r.double()).float()
+    assert rel_l2(got.cpu(), want) < 2e-5
+    plain = ops.gemm(a.bfloat16().to(DEV), w.bfloat16().to(DEV), None, r.to(DEV), out_f32=True)
+    assert rel_l2(plain.cpu(), want) > 20 * rel_l2(got.cpu(), want)
+
+
 # ------------------------------------------------------------------ elementwise
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_geglu_concat_add_cast(dtype):
@@ -212,8 +244,8 @@ def test_gemm(dtype, M, N, K, bias, res, act):
     got = ops.gemm(a.to(dtype).to(DEV), w.to(dtype).to(DEV), dev(b), None if r is None else r.to(dtype).to(DEV), act)
     assert got.dtype == dtype
     assert rel_l2(got.float().cpu(), want) < tol(dtype, 2e-6, 4e-3)
-    if dtype == torch.bfloat16:   # f32 output from bf16 operands keeps the accumulator's precision
-        got32 = ops.gemm(a.to(dtype).to(DEV), w.to(dtype).to(DEV), dev(b), None if r is None else r.to(dtype).to(DEV), act, out_f32=True)
+    if dtype == torch.bfloat16:   # f32 output (+ f32 residual: the f32-trunk form) keeps the accumulator's precision
+        got32 = ops.gemm(a.to(dtype).to(DEV), w.to(dtype).to(DEV), dev(b), dev(r), act, out_f32=True)
         assert got32.dtype == torch.float32 and rel_l2(got32.cpu(), want) < 2e-5
 
 

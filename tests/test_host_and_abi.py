@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     handle = ctypes.CDLL(_lib.LIB_PATH)
     for name in declared:
         assert hasattr(handle, name), name
-    assert _lib.lib().sdamd_abi_version() == 1
+    assert _lib.lib().sdamd_abi_version() == 2
     assert _lib.lib().sdamd_gemm_tile(65536, 320, 1) == 128064
 
 
