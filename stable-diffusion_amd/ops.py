@@ -49,8 +49,19 @@ class LaunchTimer:
     def summary(self):
         torch.cuda.synchronize()
         out = {}
-        for kind, work, s, e in self.records:
+        for kind, work, s, e, _ in self.records:
             ent = out.setdefault(kind, {"launches": 0, "ms": 0.0, "work": 0.0})
+            ent["launches"] += 1
+            ent["ms"] += s.elapsed_time(e)
+            ent["work"] += work
+        return out
+
+    def by_shape(self):
+        """{(kind, shape): {"launches", "ms", "work"}} -- per problem size, for tuning."""
+        torch.cuda.synchronize()
+        out = {}
+        for kind, work, s, e, shape in self.records:
+            ent = out.setdefault((kind, shape), {"launches": 0, "ms": 0.0, "work": 0.0})
             ent["launches"] += 1
             ent["ms"] += s.elapsed_time(e)
             ent["work"] += work
@@ -60,7 +71,7 @@ class LaunchTimer:
 PROFILER = None
 
 
-def _timed(kind, work, launch):
+def _timed(kind, work, launch, shape=""):
     prof = PROFILER
     if prof is None:
         return launch()
@@ -68,7 +79,7 @@ def _timed(kind, work, launch):
     s.record()
     r = launch()
     e.record()
-    prof.records.append((kind, float(work), s, e))
+    prof.records.append((kind, float(work), s, e, shape))
     return r
 
 
@@ -153,7 +164,8 @@ def groupnorm(x, gamma, beta, eps, silu, out_dtype=None):
     ws = _groupnorm_ws(B, x.device)
     _timed(f"groupnorm_{_dt(x.dtype)}", x.numel() * (2 * x.element_size() + y.element_size()),   # stats read + apply read + write
            lambda: _lib.check(_lib.lib().sdamd_groupnorm_nhwc(_p(x), _p(y), _p(gamma), _p(beta), _p(ws), B, HW, C, float(eps),
-                                                              int(silu), _code(x.dtype), _code(out_dtype), _stream())))
+                                                              int(silu), _code(x.dtype), _code(out_dtype), _stream())),
+           f"B{B} HW{HW} C{C}")
     return y
 
 
@@ -166,7 +178,8 @@ def layernorm(x, gamma, beta, eps=1e-5, out_dtype=None):
     y = torch.empty(x.shape, dtype=out_dtype, device=x.device)
     _timed(f"layernorm_{_dt(x.dtype)}", x.numel() * (x.element_size() + y.element_size()),
            lambda: _lib.check(_lib.lib().sdamd_layernorm(_p(x), _p(y), _p(gamma), _p(beta), x.numel() // C, C, float(eps),
-                                                         _code(x.dtype), _code(out_dtype), _stream())))
+                                                         _code(x.dtype), _code(out_dtype), _stream())),
+           f"rows{x.numel() // C} C{C}")
     return y
 
 
@@ -188,7 +201,8 @@ def geglu(x):
     Fh = x.shape[-1] // 2
     out = torch.empty(x.shape[:-1] + (Fh,), dtype=x.dtype, device=x.device)
     _timed(f"geglu_{_dt(x.dtype)}", (x.numel() + out.numel()) * x.element_size(),
-           lambda: _lib.check(_lib.lib().sdamd_geglu(_p(x), _p(out), x.numel() // (2 * Fh), Fh, _code(x.dtype), _stream())))
+           lambda: _lib.check(_lib.lib().sdamd_geglu(_p(x), _p(out), x.numel() // (2 * Fh), Fh, _code(x.dtype), _stream())),
+           f"rows{x.numel() // (2 * Fh)} F{Fh}")
     return out
 
 
@@ -259,7 +273,8 @@ def split_hilo(x):
     K = x.shape[-1]
     out = torch.empty(x.shape[:-1] + (2 * K,), dtype=torch.bfloat16, device=x.device)
     _timed("split_hilo", x.numel() * 8,
-           lambda: _lib.check(_lib.lib().sdamd_split_hilo(_p(x), _p(out), x.numel() // K, K, _stream())))
+           lambda: _lib.check(_lib.lib().sdamd_split_hilo(_p(x), _p(out), x.numel() // K, K, _stream())),
+           f"rows{x.numel() // K} K{K}")
     return out
 
 
@@ -352,7 +367,8 @@ def gemm(a, w, bias=None, residual=None, act=ACT_NONE, out_f32=False):
         assert bias.dtype == torch.float32 and bias.numel() == N and bias.is_contiguous()
     _timed(f"gemm_{_dt(a.dtype)}_{_tile_tag(M, N)}" if PROFILER is not None else "", 2.0 * M * N * K,
            lambda: _lib.check(_lib.lib().sdamd_gemm(_p(a), _p(w), _p(out), _p(bias), _p(residual), M, N, K, lda, K, N, ldr, 1,
-                                                    0, 0, 0, 0, int(act), _code(a.dtype), int(out_f32), _stream())))
+                                                    0, 0, 0, 0, int(act), _code(a.dtype), int(out_f32), _stream())),
+           f"M{M} N{N} K{K}{' +res' if residual is not None else ''}{' f32out' if out_f32 else ''}")
     return out
 
 
@@ -390,7 +406,8 @@ def conv3x3(x, w, bias, residual=None, stride=1, pad_mode=0, upsample=False, act
     _timed(f"conv3x3_{_dt(x.dtype)}_{_tile_tag(M, Cout)}" if PROFILER is not None else "", 2.0 * M * Cout * 9 * Cin,
            lambda: _lib.check(_lib.lib().sdamd_conv3x3(_p(x), _p(w), _p(out), _p(bias), _p(residual), B, H, W, Cin, Cout, stride,
                                                        pad_mode, int(upsample), int(act), _code(x.dtype), int(out_f32),
-                                                       _stream())))
+                                                       _stream())),
+           f"M{M} N{Cout} K{9 * Cin} s{stride}{' up' if upsample else ''}{' +res' if residual is not None else ''}{' f32out' if out_f32 else ''}")
     return out
 
 
@@ -434,7 +451,8 @@ def attention(q, k, v, n_heads, causal=False):
            lambda: _lib.check(_lib.lib().sdamd_attention(_p(q), _p(k), _p(v), _p(out), B, n_heads, Sq, Skv, d,
                                                          q.stride(0), q.stride(1), k.stride(0), k.stride(1), v.stride(0),
                                                          v.stride(1), out.stride(0), out.stride(1), int(causal),
-                                                         _code(q.dtype), _stream())))
+                                                         _code(q.dtype), _stream())),
+           f"B{B} H{n_heads} Sq{Sq} Skv{Skv} d{d}")
     return out
 
 
