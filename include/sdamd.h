@@ -100,21 +100,28 @@ int sdamd_vae_sample(const float* x, const float* noise, float* out, const float
 /* ---- MFMA GEMM: nn.Linear / conv1x1 (attention.py:19-20,81-85; diffusion.py:18,54,82-85,
  * 156-157; clip.py:45-46).  C[m][n] = act(sum_k A[m][k]*W[n][k] + bias[n] + residual[m][n]);
  * K % 64 == 0, N % 16 == 0; `batch` independent problems with element strides.  C and the
- * residual share one type: f32 when out_f32 (or dtype f32), else bf16. */
+ * residual share one type: f32 when out_f32 (or dtype f32), else bf16.  `ws` (may be null) is
+ * caller-owned scratch of ws_bytes for split-K partial sums: small-M / large-K problems then
+ * spread K over more workgroups and a reduce kernel applies bias/residual/act. */
 int sdamd_gemm(const void* A, const void* W, void* C, const float* bias, const void* residual, int M,
                int N, int K, int lda, int ldw, int ldc, int ldr, int batch, long long strideA,
                long long strideW, long long strideC, long long strideR, int act, int dtype,
-               int out_f32, void* stream);
-/* block tile the GEMM/conv launcher picks for an M x N problem (BM*1000+BN); host-only helper
+               int out_f32, void* ws, size_t ws_bytes, void* stream);
+/* block tile the GEMM/conv launcher picks for a problem (BM*1000+BN + 1000000*(splits-1)); host-only helper
  * used by bench.py to attribute launches to kernel instantiations (no reference counterpart) */
-int sdamd_gemm_tile(int M, int N, int batch);
+int sdamd_gemm_tile(int M, int N, int K, int batch, int dtype, size_t ws_bytes);
+/* kernel family switch for tests/benchmarks: 0 = auto (8-wave LDS-DMA bf16 kernels where they fit,
+ * else the 4-wave register-staged ones), 1 = 4-wave kernels only, 2 = 8-wave kernels whenever
+ * one of their tiles divides N, 3 = as 2 with a 3-way K split (small-size parity tests);
+ * returns the previous value */
+int sdamd_set_gemm_impl(int impl);
 /* ---- implicit-GEMM conv3x3 over NHWC: nn.Conv2d(k=3) of diffusion.py:9,13,146,204-221,
  * decoder.py:10-13,92-111, encoder.py:13-45.  w [Cout][ky][kx][Cin]; pad_mode 0 = pad 1,
  * 1 = bottom/right pad only (encoder.py:65-66); upsample=1 fuses F.interpolate(nearest,2x)
  * (diffusion.py:148-150, decoder.py:90); residual [B][Ho][Wo][Cout] or null. */
 int sdamd_conv3x3(const void* x, const void* w, void* y, const float* bias, const void* residual,
                   int B, int H, int W, int Cin, int Cout, int stride, int pad_mode, int upsample,
-                  int act, int dtype, int out_f32, void* stream);
+                  int act, int dtype, int out_f32, void* ws, size_t ws_bytes, void* stream);
 /* first convs (diffusion.py:196, decoder.py:78, encoder.py:10): x NCHW f32, Cin 3|4,
  * w [ky][kx][Cin][Cout] f32 -> y NHWC dtype */
 int sdamd_conv3x3_cin_small(const float* x_nchw, const float* w_tap_ci_co, const float* bias,

@@ -1,0 +1,440 @@
+// 8-wave bf16 MFMA GEMM / implicit-GEMM conv3x3 for gfx950 with LDS-DMA staging.
+//
+//   out[m][n] = act( sum_k A[m][k] * W[n][k] + bias[n] + residual[m][n] )       (same contract as
+//   gemm_conv.hip; this file is the fast path for the bf16 problem sizes of the SD UNet / VAE)
+//
+// Workgroup = 512 threads = 8 waves (2 per SIMD) arranged WGM x WGN over a BM x BN output tile,
+// one workgroup per CU.  K-tile = 64 bf16 = 128 bytes per row.  Both operands are K-contiguous
+// and go global -> LDS directly with global_load_lds_dwordx4 (no VGPR round trip, no ds_write):
+// one wave-instruction lands 8 rows x 128 B = 1 KiB, lane l -> row l>>3, 16-byte chunk l&7.
+// The LDS image is linear per instruction, so the bank-conflict swizzle (chunk ^= (row>>1)&7,
+// conflict-free for the ds_read_b128 lane groups of the 16x16x32 MFMA operands) is applied to
+// the SOURCE chunk each lane fetches and again on the fragment reads.
+// Conv: the A row of output pixel m at K-tile (tap, c0) is 128 contiguous bytes of the NHWC
+// input (or of a zero page when the tap falls into the padding), so the gather is just a
+// per-lane source address; stride 1/2, symmetric or bottom/right padding and the fused nearest-2x
+// upsample are address arithmetic.
+// Pipeline: a ring of STAGES LDS buffers, one workgroup barrier per K-tile:
+//     wait until tile t has landed (counted vmcnt: tile t+1 .. t+STAGES-2 stay in flight)
+//     s_barrier          (tile t visible to every wave; every wave is done with tile t-1)
+//     issue the DMA of tile t+STAGES-1 into the buffer tile t-1 just vacated
+//     ds_read + MFMA on tile t
+// The barrier is a raw s_barrier with hand-counted s_waitcnt (a __syncthreads() would drain vmcnt to
+// 0 and serialise DMA and MFMA: measured, each alone runs at ~1.5 PF-equivalent, two stages with a
+// full drain per tile only reach 1.0-1.2).  The K loop is unrolled STAGES times so that buffer
+// addresses are compile-time.  MFMA "A" = weight rows, "B" = activation rows: a lane ends up with 4 consecutive
+// output channels of one row (vector bias / residual / store), as in gemm_conv.hip.
+#include "gemm_common.h"
+#include <type_traits>
+#include <utility>
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void gbl_void_t;
+
+// 16-byte source for conv taps that fall into the zero padding
+__device__ __attribute__((aligned(256))) const unsigned int g_zero_page[64] = {0};
+
+__device__ __forceinline__ int swz2(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() {
+  static_assert(N >= 0 && N < 64, "vmcnt range");
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int BM, int BN, int WGM, int WGN, int STAGES, bool CONV>
+__global__ __launch_bounds__(WGM* WGN * 64) void gemm2_kernel(const GemmArgs p) {
+  constexpr int NW = WGM * WGN;
+  constexpr int WTM = BM / WGM, WTN = BN / WGN;  // per-wave output tile
+  constexpr int TM = WTM / 16, TN = WTN / 16;    // 16x16 MFMA tiles per wave
+  // 1-KiB DMA pieces (8 rows) per K-tile: piece g of A (or B) belongs to wave g % NW; when the
+  // piece count does not divide, the last round is predicated on the (scalar) wave id
+  constexpr int A_PIECES = BM / 8, B_PIECES = BN / 8;
+  constexpr int A_INS = (A_PIECES + NW - 1) / NW, B_INS = (B_PIECES + NW - 1) / NW;
+  constexpr int MIN_PIECES = A_PIECES / NW + B_PIECES / NW;   // fewest pieces any wave issues per tile
+  constexpr int NPIECE = A_INS + B_INS;
+  constexpr int STAGE = (BM + BN) * 128;
+  static_assert(BM % 8 == 0 && BN % 8 == 0 && WTM % 16 == 0 && WTN % 16 == 0 && (STAGES == 2 || STAGES == 3), "tile shape");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  // XCD-aware (bijective) tile order, n fastest: an XCD's run of tiles shares A rows and the W panel
+  const int nwg = gridDim.x;
+  int bid = blockIdx.x;
+  {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int tn = bid % p.tiles_n, tm = bid / p.tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int batch = blockIdx.y;   // (split-K launches have batch == 1 and use blockIdx.z = split)
+  const bf16_t* __restrict__ A = (const bf16_t*)p.A + (size_t)batch * p.sA;
+  const bf16_t* __restrict__ W = (const bf16_t*)p.W + (size_t)batch * p.sW;
+
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int rr = lane >> 3, cl = lane & 7;
+
+  // per-lane DMA sources: piece i of this wave covers tile rows (wave + NW*i)*8 .. +7
+  const bf16_t* wsrc[B_INS];
+#pragma unroll
+  for (int i = 0; i < B_INS; ++i) {
+    const int row = min(wave + NW * i, B_PIECES - 1) * 8 + rr;
+    const int n = min(n0 + row, p.N - 1);
+    wsrc[i] = W + (size_t)n * p.ldw + ((cl ^ ((row >> 1) & 7)) << 3);
+  }
+  const bf16_t* asrc[A_INS];  // dense: row pointer (+ swizzled chunk); conv: image base (+ chunk)
+  int ay[A_INS], ax[A_INS];   // conv: top-left input coordinate of the 3x3 window (upsampled grid)
+#pragma unroll
+  for (int i = 0; i < A_INS; ++i) {
+    const int row = min(wave + NW * i, A_PIECES - 1) * 8 + rr;
+    const int m = min(m0 + row, p.M - 1);
+    const int coff = (cl ^ ((row >> 1) & 7)) << 3;
+    if (CONV) {
+      const int hw = p.Ho * p.Wo;
+      const int n_img = m / hw, rem = m - n_img * hw;
+      const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+      ay[i] = oy * p.stride - p.pad;
+      ax[i] = ox * p.stride - p.pad;
+      asrc[i] = A + (size_t)n_img * p.H * p.Wd * p.Cin + coff;
+    } else {
+      asrc[i] = A + (size_t)m * p.lda + coff;
+      ay[i] = ax[i] = 0;
+    }
+  }
+  const int Hin = p.H << p.ups, Win = p.Wd << p.ups;
+  const bf16_t* zsrc = reinterpret_cast<const bf16_t*>(g_zero_page) + (cl << 3);
+
+  // this workgroup's K-tiles: [kt_begin, kt_begin + nk)
+  const int nk_total = p.K >> 6;
+  const int split = blockIdx.z;
+  const int kt_begin = (int)((long long)nk_total * split / p.splits);
+  const int nk = (int)((long long)nk_total * (split + 1) / p.splits) - kt_begin;
+  int tap = 0, cc = 0;  // conv K position of the next tile to stage: filter tap, channel offset
+  if (CONV) { const int kpt = p.Cin >> 6; tap = kt_begin / kpt; cc = (kt_begin - tap * kpt) << 6; }
+  // DMA piece PI (compile-time) of the tile at K offset k0 / conv position (ky, kx, cc)
+  auto stage_piece = [&](auto PIC, char* stage, int k0, int ky, int kx) {
+    constexpr int PI = decltype(PIC)::value;
+    if constexpr (PI < A_INS) {
+      constexpr int i = PI;
+      if (A_PIECES % NW != 0 && i == A_INS - 1 && wave + NW * i >= A_PIECES) return;
+      const bf16_t* g;
+      if (CONV) {
+        const int iy = ay[i] + ky, ix = ax[i] + kx;
+        const bool ok = (unsigned)iy < (unsigned)Hin && (unsigned)ix < (unsigned)Win;
+        g = ok ? asrc[i] + ((size_t)(iy >> p.ups) * p.Wd + (ix >> p.ups)) * p.Cin + cc : zsrc;
+      } else {
+        g = asrc[i] + k0;
+      }
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)g, (lds_void_t*)(stage + (wave + NW * i) * 1024), 16, 0, 0);
+    } else {
+      constexpr int i = PI - A_INS;
+      if (B_PIECES % NW != 0 && i == B_INS - 1 && wave + NW * i >= B_PIECES) return;
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)(wsrc[i] + k0), (lds_void_t*)(stage + BM * 128 + (wave + NW * i) * 1024), 16, 0, 0);
+    }
+  };
+  auto advance_k = [&]() { if (CONV) { cc += 64; if (cc >= p.Cin) { cc = 0; ++tap; } } };
+  auto stage_tile = [&](char* stage, int k0) {   // all pieces back to back (prologue)
+    if (p.debug == 1) return;
+    int ky = 0, kx = 0;
+    if (CONV) { ky = tap / 3; kx = tap - ky * 3; }
+    [&]<int... PI>(std::integer_sequence<int, PI...>) { (stage_piece(std::integral_constant<int, PI>{}, stage, k0, ky, kx), ...); }
+    (std::make_integer_sequence<int, NPIECE>{});
+    advance_k();
+  };
+
+  f32x4_t acc[TN][TM];
+#pragma unroll
+  for (int j = 0; j < TN; ++j)
+#pragma unroll
+    for (int i = 0; i < TM; ++i) acc[j][i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  const int r16 = lane & 15, q4 = lane >> 4;
+  // MFMAs of one K-tile; optionally (INTERLEAVE_DMA) with the DMA pieces of a later tile spread
+  // between the MFMA groups instead of issued back to back ahead of them.  Measured: no gain on the
+  // 8-wave tiles and -25 % on the 4-wave 128x160 tile, so it is off; the limiter of the K loop is the
+  // L2 -> LDS fill rate (~60 GB/s per CU), i.e. bytes per FLOP, i.e. the tile size.
+  constexpr bool INTERLEAVE_DMA = false;
+  auto compute_tile = [&](const char* stage, char* next_stage, bool do_stage, int k0) {
+    const char* sa = stage;
+    const char* sw = stage + BM * 128;
+    int ky = 0, kx = 0;
+    if (CONV) { ky = tap / 3; kx = tap - ky * 3; }
+    if (p.debug == 1) do_stage = false;
+    constexpr int NGROUP = 2 * TN;
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      bf16x8_t xf[TM], wf[TN];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) wf[j] = *reinterpret_cast<const bf16x8_t*>(sw + swz2(wn * WTN + j * 16 + r16, 4 * g + q4));
+#pragma unroll
+      for (int i = 0; i < TM; ++i) xf[i] = *reinterpret_cast<const bf16x8_t*>(sa + swz2(wm * WTM + i * 16 + r16, 4 * g + q4));
+      [&]<int... J>(std::integer_sequence<int, J...>) {
+        ([&] {
+          constexpr int j = J;
+          if (p.debug != 2) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc[j][i], 0, 0, 0);
+          }
+          // pieces assigned to MFMA group q = g*TN + j: those with PI*NGROUP/NPIECE == q
+          [&]<int... PI>(std::integer_sequence<int, PI...>) {
+            ([&] {
+              if constexpr (PI * NGROUP / NPIECE == 0 * TN + j) { if (g == 0 && do_stage) stage_piece(std::integral_constant<int, PI>{}, next_stage, k0, ky, kx); }
+              if constexpr (PI * NGROUP / NPIECE == 1 * TN + j) { if (g == 1 && do_stage) stage_piece(std::integral_constant<int, PI>{}, next_stage, k0, ky, kx); }
+            }(), ...);
+          }(std::make_integer_sequence<int, NPIECE>{});
+        }(), ...);
+      }(std::make_integer_sequence<int, TN>{});
+    }
+    if (do_stage) advance_k();
+  };
+
+  // main loop (see the header): tile t lives in ring buffer t % STAGES
+#define GEMM2_STEP(BUF, NEXTBUF)                                                         \
+  {                                                                                      \
+    if (kt + STAGES - 1 <= nk) wait_vmcnt<(STAGES - 2) * MIN_PIECES>(); else wait_vmcnt<0>(); \
+    __builtin_amdgcn_s_barrier();                                                        \
+    if (INTERLEAVE_DMA) {                                                                \
+      compute_tile(smem + (BUF) * STAGE, smem + (NEXTBUF) * STAGE, kt + STAGES - 1 < nk, (kt_begin + kt + STAGES - 1) << 6); \
+    } else {                                                                             \
+      if (kt + STAGES - 1 < nk) stage_tile(smem + (NEXTBUF) * STAGE, (kt_begin + kt + STAGES - 1) << 6); \
+      compute_tile(smem + (BUF) * STAGE, nullptr, false, 0);                             \
+    }                                                                                    \
+    if (++kt >= nk) break;                                                               \
+  }
+  int kt = 0;
+  stage_tile(smem, kt_begin << 6);
+  if (STAGES == 3 && nk > 1) stage_tile(smem + STAGE, (kt_begin + 1) << 6);
+  if (STAGES == 2) {
+    for (;;) {
+      GEMM2_STEP(0, 1)
+      GEMM2_STEP(1, 0)
+    }
+  } else {
+    for (;;) {
+      GEMM2_STEP(0, 2)
+      GEMM2_STEP(1, 0)
+      GEMM2_STEP(2, 1)
+    }
+  }
+#undef GEMM2_STEP
+
+  if (p.splits > 1) {  // raw f32 partial sums; bias / residual / activation happen in splitk_reduce_kernel
+    float* __restrict__ ws = p.ws + (size_t)split * p.M * p.N;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int m = m0 + wm * WTM + i * 16 + r16;
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * WTN + j * 16 + q4 * 4;
+        if (n >= p.N) continue;
+        *reinterpret_cast<f32x4_t*>(ws + (size_t)m * p.N + n) = acc[j][i];
+      }
+    }
+    return;
+  }
+
+  // Epilogue.  A lane holds out[m][n..n+3] for 4 x TM x TN scattered (m, n): stored directly that is
+  // 8-16 bytes per lane at a row stride, which is store-issue bound (measured: the K=320 GEMMs spent
+  // more time here than in the K loop).  Instead every wave transposes its WTM x WTN sub-tile
+  // through its own slice of the (now idle) staging LDS and writes whole row segments, 16 bytes per
+  // lane, consecutive lanes on consecutive addresses.  No workgroup barrier is needed after the one
+  // below: a wave only reads back what it wrote itself, and LDS operations of one wave complete in
+  // order.
+  __syncthreads();  // every wave is done reading the last K-tile (and no DMA is outstanding)
+  const float* __restrict__ bias = p.bias;
+  const int mw = m0 + wm * WTM, nw = n0 + wn * WTN;  // this wave's sub-tile origin
+  if (p.out_f32) {
+    constexpr int RS = WTN * 4 + 16;                     // padded LDS row stride (bytes)
+    constexpr int IPMAX = (STAGES * STAGE / NW) / (16 * RS);  // 16-row tiles per pass that fit the wave's slice
+    constexpr int IP = IPMAX >= TM ? TM : (IPMAX >= TM / 2 && TM % 2 == 0) ? TM / 2 : (IPMAX >= TM / 4 && TM % 4 == 0) ? TM / 4 : 1;
+    static_assert(IPMAX >= 1, "epilogue staging does not fit");
+    constexpr int CPR = WTN / 4;  // 16-byte chunks per row
+    char* const slice = smem + wave * (IP * 16 * RS);
+    const float* __restrict__ Rf = p.R ? (const float*)p.R + (size_t)batch * p.sR : nullptr;
+    float* __restrict__ C = (float*)p.C + (size_t)batch * p.sC;
+#pragma unroll
+    for (int ps = 0; ps < TM / IP; ++ps) {
+#pragma unroll
+      for (int ii = 0; ii < IP; ++ii) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          f32x4_t v = acc[j][ps * IP + ii];
+          const int n = nw + j * 16 + q4 * 4;
+          if (bias && n < p.N) v += *reinterpret_cast<const f32x4_t*>(bias + n);
+          *reinterpret_cast<f32x4_t*>(slice + (ii * 16 + r16) * RS + (j * 16 + q4 * 4) * 4) = v;
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      for (int idx = lane; idx < IP * 16 * CPR; idx += 64) {
+        const int row = idx / CPR, ch = idx - row * CPR;
+        const int m = mw + ps * IP * 16 + row, n = nw + ch * 4;
+        f32x4_t v = *reinterpret_cast<const f32x4_t*>(slice + row * RS + ch * 16);
+        if (m < p.M && n < p.N) {
+          if (Rf) v += *reinterpret_cast<const f32x4_t*>(Rf + (size_t)m * p.ldr + n);
+          if (p.act == ACT_QUICK_GELU) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = quick_gelu_f(v[r]);
+          } else if (p.act == ACT_SILU) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = silu_f(v[r]);
+          }
+          *reinterpret_cast<f32x4_t*>(C + (size_t)m * p.ldc + n) = v;
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  } else {
+    constexpr int RS = WTN * 2 + 16;
+    constexpr int IPMAX = (STAGES * STAGE / NW) / (16 * RS);
+    constexpr int IP = IPMAX >= TM ? TM : (IPMAX >= TM / 2 && TM % 2 == 0) ? TM / 2 : (IPMAX >= TM / 4 && TM % 4 == 0) ? TM / 4 : 1;
+    static_assert(IPMAX >= 1, "epilogue staging does not fit");
+    constexpr int CPR = WTN / 8;
+    char* const slice = smem + wave * (IP * 16 * RS);
+    const bf16_t* __restrict__ R = p.R ? (const bf16_t*)p.R + (size_t)batch * p.sR : nullptr;
+    bf16_t* __restrict__ C = (bf16_t*)p.C + (size_t)batch * p.sC;
+#pragma unroll
+    for (int ps = 0; ps < TM / IP; ++ps) {
+#pragma unroll
+      for (int ii = 0; ii < IP; ++ii) {
+        const int m = mw + (ps * IP + ii) * 16 + r16;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          f32x4_t v = acc[j][ps * IP + ii];
+          const int n = nw + j * 16 + q4 * 4;
+          if (bias && n < p.N) v += *reinterpret_cast<const f32x4_t*>(bias + n);
+          if (R && m < p.M && n < p.N) {   // (bf16 residual trunks are the rare case: added before rounding)
+            const u32x2_t rv = *reinterpret_cast<const u32x2_t*>(R + (size_t)m * p.ldr + n);
+            v[0] += __builtin_bit_cast(float, rv[0] << 16); v[1] += __builtin_bit_cast(float, rv[0] & 0xffff0000u);
+            v[2] += __builtin_bit_cast(float, rv[1] << 16); v[3] += __builtin_bit_cast(float, rv[1] & 0xffff0000u);
+          }
+          if (p.act == ACT_QUICK_GELU) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = quick_gelu_f(v[r]);
+          } else if (p.act == ACT_SILU) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = silu_f(v[r]);
+          }
+          const u32x2_t o = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+          *reinterpret_cast<u32x2_t*>(slice + (ii * 16 + r16) * RS + (j * 16 + q4 * 4) * 2) = o;
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      for (int idx = lane; idx < IP * 16 * CPR; idx += 64) {
+        const int row = idx / CPR, ch = idx - row * CPR;
+        const int m = mw + ps * IP * 16 + row, n = nw + ch * 8;
+        const u32x4_t v = *reinterpret_cast<const u32x4_t*>(slice + row * RS + ch * 16);
+        if (m < p.M && n < p.N) *reinterpret_cast<u32x4_t*>(C + (size_t)m * p.ldc + n) = v;
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+}
+
+// out = act(sum_s ws[s] + bias + residual): the epilogue of a split-K launch; one thread = 4 columns
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
+  const int nq = p.N >> 2;
+  const size_t total = (size_t)p.M * nq;
+  const size_t slab = (size_t)p.M * p.N;
+  for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+    const size_t m = idx / nq;
+    const int n = (int)(idx - m * nq) << 2;
+    f32x4_t v = *reinterpret_cast<const f32x4_t*>(p.ws + m * p.N + n);
+    for (int s = 1; s < p.splits; ++s) v += *reinterpret_cast<const f32x4_t*>(p.ws + s * slab + m * p.N + n);
+    if (p.bias) v += *reinterpret_cast<const f32x4_t*>(p.bias + n);
+    if (p.R) {
+      if (p.out_f32) {
+        v += *reinterpret_cast<const f32x4_t*>((const float*)p.R + m * p.ldr + n);
+      } else {
+        const u32x2_t rv = *reinterpret_cast<const u32x2_t*>((const bf16_t*)p.R + m * p.ldr + n);
+        v[0] += __builtin_bit_cast(float, rv[0] << 16); v[1] += __builtin_bit_cast(float, rv[0] & 0xffff0000u);
+        v[2] += __builtin_bit_cast(float, rv[1] << 16); v[3] += __builtin_bit_cast(float, rv[1] & 0xffff0000u);
+      }
+    }
+    if (p.act == ACT_QUICK_GELU) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = quick_gelu_f(v[r]);
+    } else if (p.act == ACT_SILU) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = silu_f(v[r]);
+    }
+    if (p.out_f32) {
+      *reinterpret_cast<f32x4_t*>((float*)p.C + m * p.ldc + n) = v;
+    } else {
+      const u32x2_t o = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+      *reinterpret_cast<u32x2_t*>((bf16_t*)p.C + m * p.ldc + n) = o;
+    }
+  }
+}
+
+template <int BM, int BN, int WGM, int WGN, int STAGES, bool CONV>
+static int launch2(GemmArgs& a, int batch, hipStream_t st) {
+  a.tiles_m = (a.M + BM - 1) / BM;
+  a.tiles_n = (a.N + BN - 1) / BN;
+  constexpr int lds = STAGES * (BM + BN) * 128;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)gemm2_kernel<BM, BN, WGM, WGN, STAGES, CONV>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+      return sdamd_set_error(2, "gemm2: cannot reserve %d bytes of LDS", lds);
+    attr_set = true;
+  }
+  dim3 grid(a.tiles_m * a.tiles_n, batch, a.splits);
+  gemm2_kernel<BM, BN, WGM, WGN, STAGES, CONV><<<grid, WGM * WGN * 64, lds, st>>>(a);
+  SD_LAUNCH_CHECK("gemm2");
+  if (a.splits > 1) {
+    size_t items = (size_t)a.M * (a.N >> 2);
+    int g = (int)((items + 255) / 256 > 2048 ? 2048 : (items + 255) / 256);
+    splitk_reduce_kernel<<<g, 256, 0, st>>>(a);
+    SD_LAUNCH_CHECK("splitk_reduce");
+  }
+  return 0;
+}
+
+// Tile and split-K plan.  Tile family: 128x320 / 128x160 (every UNet channel count is a multiple of
+// 320; the 160-wide tile runs as two 4-wave workgroups per CU and doubles the tile count of the
+// low-resolution levels) and 256x256 (VAE / CLIP).  When even the small tile leaves most CUs idle
+// (8x8 / 16x16 feature maps with K = 9*Cin up to 23040), K is split across grid.z and a reduce
+// kernel finishes the epilogue; that needs the caller's workspace.
+// mode: 0 = auto, 2 = any fitting tile however few workgroups, 3 = as 2 plus a 3-way K split.
+// Returns BM*1000+BN (0: use the 4-wave kernels of gemm_conv.hip) and *splits.
+int gemm2_choose_tile(int M, int N, int K, int batch, int mode, size_t ws_bytes, int* splits) {
+  auto blocks = [&](int bm, int bn) { return (long long)((M + bm - 1) / bm) * ((N + bn - 1) / bn) * batch; };
+  const int nk = K >> 6;
+  const size_t slab = (size_t)M * N * sizeof(float);
+  auto max_splits = [&]() { return (batch == 1 && slab > 0) ? (int)(ws_bytes / slab) : 1; };
+  *splits = 1;
+  if (mode >= 2) {
+    int tile = N % 320 == 0 ? 128320 : N % 160 == 0 ? 128160 : N % 256 == 0 ? 256256 : 0;
+    if (tile && mode == 3 && nk >= 3 && max_splits() >= 3) *splits = 3;
+    return tile;
+  }
+  extern int g_gemm_debug;
+  if (g_gemm_debug == 4 && N % 160 == 0 && blocks(256, 160) >= 256) return 256160;   // experiment: 3-stage ring
+  if (N % 320 == 0 && blocks(128, 320) >= 256) return 128320;
+  if (N % 160 == 0) {
+    const long long b = blocks(128, 160);
+    if (b >= 192) return 128160;
+    int s = (int)((256 + b - 1) / b);
+    if (s > 8) s = 8;
+    if (s > nk / 4) s = nk / 4;
+    if (s > max_splits()) s = max_splits();
+    if (s >= 2) { *splits = s; return 128160; }
+    if (b >= 128) return 128160;
+    return 0;
+  }
+  if (N % 256 == 0 && blocks(256, 256) >= 192) return 256256;
+  return 0;
+}
+
+int launch_gemm2_bf16(GemmArgs& a, int batch, bool conv, int mode, hipStream_t st) {
+  if ((a.ldr % 4) != 0 || (a.R && ((uintptr_t)a.R % 16) != 0)) return -1;
+  if (!a.out_f32 && ((a.ldc % 8) != 0 || (a.sC % 8) != 0)) return -1;   // 16-byte row-segment stores
+  const int tile = gemm2_choose_tile(a.M, a.N, a.K, batch, mode, a.ws ? a.ws_bytes : 0, &a.splits);
+  switch (tile) {
+    case 256160: return conv ? launch2<256, 160, 4, 2, 3, true>(a, batch, st) : launch2<256, 160, 4, 2, 3, false>(a, batch, st);
+    case 128160: return conv ? launch2<128, 160, 2, 2, 2, true>(a, batch, st) : launch2<128, 160, 2, 2, 2, false>(a, batch, st);
+    case 128320: return conv ? launch2<128, 320, 2, 4, 2, true>(a, batch, st) : launch2<128, 320, 2, 4, 2, false>(a, batch, st);
+    case 256256: return conv ? launch2<256, 256, 2, 4, 2, true>(a, batch, st) : launch2<256, 256, 2, 4, 2, false>(a, batch, st);
+    default: a.splits = 1; return -1;
+  }
+}

@@ -1,0 +1,33 @@
+// Argument block shared by the MFMA GEMM / implicit-GEMM conv kernels (gemm_conv.hip, gemm2.hip).
+#pragma once
+#include "common.h"
+
+#define ACT_NONE 0
+#define ACT_QUICK_GELU 1
+#define ACT_SILU 2
+
+struct GemmArgs {
+  const void* A;     // dense: [M][lda]; conv: NHWC input [B][H][W][Cin]
+  const void* W;     // [N][ldw], K-contiguous (conv: [Cout][ky][kx][Cin])
+  void* C;           // [M][ldc]
+  const float* bias; // [N] or null
+  const void* R;     // residual [M][ldr] (same dtype as C: f32 when out_f32, else the operand dtype) or null
+  int M, N, K;
+  int lda, ldw, ldc, ldr;
+  long long sA, sW, sC, sR;  // batch strides (elements), grid.y = batch
+  int act, out_f32;
+  // conv geometry (CONV only)
+  int H, Wd, Cin, Ho, Wo, stride, pad, ups;
+  int tiles_m, tiles_n;
+  // split-K (gemm2.hip): grid.z = splits, each writes raw f32 partials to ws[split][M][N]
+  int splits;
+  float* ws;
+  size_t ws_bytes;
+  int debug;   // timing experiments only (sdamd_set_gemm_impl(impl | debug << 8)): 1 = skip the DMA, 2 = skip the MFMAs
+};
+
+
+// gemm2.hip: 8-wave, LDS-DMA-staged bf16 kernels.  Returns -1 when no tile configuration of that
+// family fits the problem (the caller then uses the 4-wave register-staged kernels), 0 on launch.
+int launch_gemm2_bf16(GemmArgs& a, int batch, bool conv, int mode, hipStream_t st);   // mode: g_gemm_impl
+int gemm2_choose_tile(int M, int N, int K, int batch, int mode, size_t ws_bytes, int* splits);

@@ -19,24 +19,7 @@
 //         issues 4 MFMAs; the k order is a permutation applied to both operands alike.
 #include "common.h"
 
-#define ACT_NONE 0
-#define ACT_QUICK_GELU 1
-#define ACT_SILU 2
-
-struct GemmArgs {
-  const void* A;     // dense: [M][lda]; conv: NHWC input [B][H][W][Cin]
-  const void* W;     // [N][ldw], K-contiguous (conv: [Cout][ky][kx][Cin])
-  void* C;           // [M][ldc]
-  const float* bias; // [N] or null
-  const void* R;     // residual [M][ldr] (same dtype as C: f32 when out_f32, else the operand dtype) or null
-  int M, N, K;
-  int lda, ldw, ldc, ldr;
-  long long sA, sW, sC, sR;  // batch strides (elements), grid.y = batch
-  int act, out_f32;
-  // conv geometry (CONV only)
-  int H, Wd, Cin, Ho, Wo, stride, pad, ups;
-  int tiles_m, tiles_n;
-};
+#include "gemm_common.h"
 
 template <typename T> struct Frag;
 template <> struct Frag<bf16_t> { typedef bf16x8_t type; };
@@ -367,7 +350,20 @@ static int choose_tile(int M, int N, int batch) {
   return 64064;
 }
 
-extern "C" int sdamd_gemm_tile(int M, int N, int batch) { return choose_tile(M, N, batch); }
+// 0 = auto (8-wave LDS-DMA kernels of gemm2.hip where a tile of that family fits, else the 4-wave
+// kernels of this file), 1 = this file only, 2 = gemm2.hip whenever one of its tiles divides N, however
+// few workgroups that makes, 3 = as 2 with a 3-way K split (parity tests at small sizes).
+static int g_gemm_impl = 0;
+int g_gemm_debug = 0;
+extern "C" int sdamd_set_gemm_impl(int impl) { int old = g_gemm_impl; g_gemm_impl = impl & 255; g_gemm_debug = impl >> 8; return old; }
+
+extern "C" int sdamd_gemm_tile(int M, int N, int K, int batch, int dtype, size_t ws_bytes) {
+  if (dtype == SDAMD_BF16 && g_gemm_impl != 1) {
+    int splits = 1;
+    if (int t2 = gemm2_choose_tile(M, N, K, batch, g_gemm_impl, ws_bytes, &splits)) return t2 + 1000000 * (splits - 1);
+  }
+  return choose_tile(M, N, batch);
+}
 
 template <typename T, bool CONV>
 static int pick_tile(GemmArgs& a, int batch, hipStream_t st) {
@@ -393,8 +389,10 @@ static int check_common(const GemmArgs& a, int dtype, const char* what) {
 
 extern "C" int sdamd_gemm(const void* A, const void* W, void* C, const float* bias, const void* residual, int M, int N, int K,
                           int lda, int ldw, int ldc, int ldr, int batch, long long strideA, long long strideW,
-                          long long strideC, long long strideR, int act, int dtype, int out_f32, void* stream) {
+                          long long strideC, long long strideR, int act, int dtype, int out_f32, void* ws,
+                          size_t ws_bytes, void* stream) {
   GemmArgs a = {};
+  a.splits = 1; a.ws = (float*)ws; a.ws_bytes = ws_bytes; a.debug = g_gemm_debug;
   a.A = A; a.W = W; a.C = C; a.bias = bias; a.R = residual;
   a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldw = ldw; a.ldc = ldc; a.ldr = ldr;
   a.sA = strideA; a.sW = strideW; a.sC = strideC; a.sR = strideR;
@@ -405,6 +403,10 @@ extern "C" int sdamd_gemm(const void* A, const void* W, void* C, const float* bi
   SD_CHECK(batch >= 1, "gemm: batch=%d", batch);
   SD_CHECK(!residual || (ldr >= N && ldr % 4 == 0 && ((uintptr_t)residual % 16) == 0), "gemm: residual needs ldr=%d >= N, ldr %% 4 == 0 and 16-byte alignment", ldr);
   hipStream_t st = (hipStream_t)stream;
+  if (dtype == SDAMD_BF16 && g_gemm_impl != 1) {
+    const int r = launch_gemm2_bf16(a, batch, false, g_gemm_impl, st);
+    if (r >= 0) return r;
+  }
   if (dtype == SDAMD_BF16) return pick_tile<bf16_t, false>(a, batch, st);
   return pick_tile<float, false>(a, batch, st);
 }
@@ -414,7 +416,7 @@ extern "C" int sdamd_gemm(const void* A, const void* W, void* C, const float* bi
 // upsample=1 reads the input through a nearest 2x upsample (diffusion.py:148-150, decoder.py:90-111).
 extern "C" int sdamd_conv3x3(const void* x, const void* w, void* y, const float* bias, const void* residual, int B, int H,
                              int Wd, int Cin, int Cout, int stride, int pad_mode, int upsample, int act, int dtype,
-                             int out_f32, void* stream) {
+                             int out_f32, void* ws, size_t ws_bytes, void* stream) {
   SD_CHECK(stride == 1 || stride == 2, "conv3x3: stride=%d", stride);
   SD_CHECK(pad_mode == 0 || pad_mode == 1, "conv3x3: pad_mode=%d", pad_mode);
   SD_CHECK(upsample == 0 || upsample == 1, "conv3x3: upsample=%d", upsample);
@@ -428,11 +430,16 @@ extern "C" int sdamd_conv3x3(const void* x, const void* w, void* y, const float*
   a.M = B * Ho * Wo; a.N = Cout; a.K = 9 * Cin;
   a.lda = 0; a.ldw = 9 * Cin; a.ldc = Cout; a.ldr = Cout;
   a.act = act; a.out_f32 = out_f32;
+  a.splits = 1; a.ws = (float*)ws; a.ws_bytes = ws_bytes; a.debug = g_gemm_debug;
   a.H = H; a.Wd = Wd; a.Cin = Cin; a.Ho = Ho; a.Wo = Wo; a.stride = stride; a.pad = pad; a.ups = upsample;
   if (int e = check_common(a, dtype, "conv3x3")) return e;
   const int bke = dtype == SDAMD_BF16 ? 64 : 32;
   SD_CHECK(Cin % bke == 0, "conv3x3: Cin=%d must be a multiple of %d (use the small-channel kernels)", Cin, bke);
   hipStream_t st = (hipStream_t)stream;
+  if (dtype == SDAMD_BF16 && g_gemm_impl != 1) {
+    const int r = launch_gemm2_bf16(a, 1, true, g_gemm_impl, st);
+    if (r >= 0) return r;
+  }
   if (dtype == SDAMD_BF16) return pick_tile<bf16_t, true>(a, 1, st);
   return pick_tile<float, true>(a, 1, st);
 }

@@ -83,9 +83,24 @@ def _timed(kind, work, launch, shape=""):
     return r
 
 
-def _tile_tag(M, N, batch=1):
-    t = _lib.lib().sdamd_gemm_tile(M, N, batch)
-    return f"{t // 1000}x{t % 1000}"
+def _tile_tag(M, N, K, dtype, ws, batch=1):
+    t = _lib.lib().sdamd_gemm_tile(M, N, K, batch, _code(dtype), ws.numel())
+    t, s = t % 1000000, t // 1000000 + 1
+    return f"{t // 1000}x{t % 1000}" + (f"_splitk{s}" if s > 1 else "")
+
+
+_gemm_ws = {}
+GEMM_WS_BYTES = 64 << 20
+
+
+def _gemm_workspace(device):
+    """Per (device, stream) scratch for split-K partial sums (sdamd_gemm / sdamd_conv3x3 `ws`)."""
+    key = (device, torch.cuda.current_stream().cuda_stream)
+    ws = _gemm_ws.get(key)
+    if ws is None:
+        ws = torch.empty(GEMM_WS_BYTES, dtype=torch.uint8, device=device)
+        _gemm_ws[key] = ws
+    return ws
 
 
 def _dt(dtype):
@@ -365,9 +380,11 @@ def gemm(a, w, bias=None, residual=None, act=ACT_NONE, out_f32=False):
         ldr = N
     if bias is not None:
         assert bias.dtype == torch.float32 and bias.numel() == N and bias.is_contiguous()
-    _timed(f"gemm_{_dt(a.dtype)}_{_tile_tag(M, N)}" if PROFILER is not None else "", 2.0 * M * N * K,
+    ws = _gemm_workspace(a.device)
+    _timed(f"gemm_{_dt(a.dtype)}_{_tile_tag(M, N, K, a.dtype, ws)}" if PROFILER is not None else "", 2.0 * M * N * K,
            lambda: _lib.check(_lib.lib().sdamd_gemm(_p(a), _p(w), _p(out), _p(bias), _p(residual), M, N, K, lda, K, N, ldr, 1,
-                                                    0, 0, 0, 0, int(act), _code(a.dtype), int(out_f32), _stream())),
+                                                    0, 0, 0, 0, int(act), _code(a.dtype), int(out_f32), _p(ws), ws.numel(),
+                                                    _stream())),
            f"M{M} N{N} K{K}{' +res' if residual is not None else ''}{' f32out' if out_f32 else ''}")
     return out
 
@@ -381,7 +398,7 @@ def bmm_nt(a, b, out_f32=False):
     assert b.shape[0] == Bt and b.shape[2] == K
     out = torch.empty((Bt, M, N), dtype=torch.float32 if out_f32 else a.dtype, device=a.device)
     _lib.check(_lib.lib().sdamd_gemm(_p(a), _p(b), _p(out), 0, 0, M, N, K, a.stride(1), b.stride(1), N, 0, Bt, a.stride(0),
-                                     b.stride(0), M * N, 0, ACT_NONE, _code(a.dtype), int(out_f32), _stream()))
+                                     b.stride(0), M * N, 0, ACT_NONE, _code(a.dtype), int(out_f32), 0, 0, _stream()))
     return out
 
 
@@ -403,10 +420,11 @@ def conv3x3(x, w, bias, residual=None, stride=1, pad_mode=0, upsample=False, act
     if bias is not None:
         assert bias.dtype == torch.float32 and bias.numel() == Cout
     M = B * Ho * Wo
-    _timed(f"conv3x3_{_dt(x.dtype)}_{_tile_tag(M, Cout)}" if PROFILER is not None else "", 2.0 * M * Cout * 9 * Cin,
+    ws = _gemm_workspace(x.device)
+    _timed(f"conv3x3_{_dt(x.dtype)}_{_tile_tag(M, Cout, 9 * Cin, x.dtype, ws)}" if PROFILER is not None else "", 2.0 * M * Cout * 9 * Cin,
            lambda: _lib.check(_lib.lib().sdamd_conv3x3(_p(x), _p(w), _p(out), _p(bias), _p(residual), B, H, W, Cin, Cout, stride,
                                                        pad_mode, int(upsample), int(act), _code(x.dtype), int(out_f32),
-                                                       _stream())),
+                                                       _p(ws), ws.numel(), _stream())),
            f"M{M} N{Cout} K{9 * Cin} s{stride}{' up' if upsample else ''}{' +res' if residual is not None else ''}{' f32out' if out_f32 else ''}")
     return out
 

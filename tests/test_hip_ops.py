@@ -220,12 +220,22 @@ def test_softmax_rows():
 
 
 # ------------------------------------------------------------------ MFMA GEMM
+@pytest.fixture(params=[1, 2, 3], ids=["wave4", "wave8", "wave8_splitk3"])
+def gemm_impl(request):
+    """Run the test once per kernel family (gemm_conv.hip 4-wave / gemm2.hip 8-wave LDS-DMA)."""
+    from sd_amd import _lib
+    old = _lib.lib().sdamd_set_gemm_impl(request.param)
+    yield request.param
+    _lib.lib().sdamd_set_gemm_impl(old)
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("M,N,K,bias,res,act", [
     (300, 320, 320, True, True, 0), (77, 3072, 768, True, False, 1), (1, 1280, 320, True, False, 2),
     (8192, 320, 1280, True, True, 0), (130, 2560, 320, True, False, 0), (64, 1280, 5120, False, False, 0),
-    (4096, 960, 320, False, False, 0), (154, 640, 768, False, False, 0), (1000, 128, 256, True, True, 0)])
-def test_gemm(dtype, M, N, K, bias, res, act):
+    (4096, 960, 320, False, False, 0), (154, 640, 768, False, False, 0), (1000, 128, 256, True, True, 0),
+    (1111, 512, 192, True, True, 0), (3000, 2560, 320, True, False, 0)])
+def test_gemm(dtype, M, N, K, bias, res, act, gemm_impl):
     a = q(rnd(f"gemm.a.{M}.{K}", (M, K)), dtype)
     w = q(rnd(f"gemm.w.{N}.{K}", (N, K), 1.0 / math.sqrt(K)), dtype)
     b = rnd(f"gemm.b.{N}", (N,)) if bias else None
@@ -250,7 +260,7 @@ def test_gemm(dtype, M, N, K, bias, res, act):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-def test_gemm_strided_views_and_batched(dtype):
+def test_gemm_strided_views_and_batched(dtype, gemm_impl):
     qkv = q(rnd("bmm.qkv", (2, 192, 3 * 512)), dtype)
     d = qkv.to(dtype).to(DEV)
     qv, kv, vv = d[..., :512], d[..., 512:1024], d[..., 1024:]
@@ -267,8 +277,8 @@ def test_gemm_strided_views_and_batched(dtype):
     (1, 320, 320, 16, 16, 2, 0, False, False), (1, 128, 128, 16, 16, 2, 1, False, False),
     (1, 640, 640, 8, 8, 1, 0, True, False), (2, 1280, 640, 4, 4, 1, 0, False, True),
     (1, 128, 256, 9, 7, 1, 0, False, False), (1, 256, 256, 15, 15, 2, 1, False, False),
-    (3, 960, 320, 8, 8, 1, 0, False, False)])
-def test_conv3x3(dtype, B, Cin, Cout, H, W, stride, pad_mode, ups, res):
+    (3, 960, 320, 8, 8, 1, 0, False, False), (2, 256, 512, 13, 11, 1, 0, True, True)])
+def test_conv3x3(dtype, B, Cin, Cout, H, W, stride, pad_mode, ups, res, gemm_impl):
     x = q(rnd(f"conv.x.{Cin}.{H}", (B, Cin, H, W)), dtype)
     w = q(rnd(f"conv.w.{Cin}.{Cout}", (Cout, Cin, 3, 3), 1.0 / math.sqrt(9 * Cin)), dtype)
     b = rnd(f"conv.b.{Cout}", (Cout,))
