@@ -1,0 +1,10 @@
+import os, sys; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch, sd_amd
+from sd_amd import ops
+torch.set_grad_enabled(False)
+g = torch.Generator(device="cuda").manual_seed(0)
+B, H, d, S = 16, 8, int(sys.argv[1]) if len(sys.argv) > 1 else 40, int(sys.argv[2]) if len(sys.argv) > 2 else 4096
+qkv = torch.randn(B, S, 3 * H * d, device="cuda", generator=g).bfloat16()
+C = H * d
+for _ in range(3): ops.attention(qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:], H)
+torch.cuda.synchronize()

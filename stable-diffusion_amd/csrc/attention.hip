@@ -55,6 +55,11 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs p) {
   constexpr int NB = DV / 32;                                // 32-wide output blocks
   constexpr int NSUB = BKV / 32;                             // 32-key sub-tiles per staged tile
   constexpr bool BF = sizeof(T) == 2;
+  // When the head dim leaves a spare padded V column (d = 40, 80), that column is set to one, so the
+  // P V product itself accumulates the softmax denominator (from the same rounded P as the
+  // numerator) and the online rescale of O covers it: no per-score adds, no cross-half exchange.
+  constexpr bool ONES = D < DV;
+  constexpr int L_BLK = D / 32, L_REG = ((D % 32) & 3) + 4 * ((D % 32) >> 3), L_HALF = ((D % 32) >> 2) & 1;
   constexpr int NQ = BF ? DK / 16 : D / 8;                   // Q fragments (4 VGPR each)
   constexpr int KCH = BKV * KC, VCH = BKV * VC;              // chunks per staged tile
   constexpr int KPT = (KCH + 255) / 256, VPT = (VCH + 255) / 256;
@@ -100,6 +105,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs p) {
       const int c = t + 256 * i;
       const int row = c / VC, ch = c - row * VC;
       u32x4_t z = {0u, 0u, 0u, 0u};
+      if (ONES && ch == DC) z[0] = BF ? 0x00003F80u : 0x3F800000u;   // V[:, D] = 1: O^T row D accumulates the row sums
       if (c < VCH && ch < DC && kv0 + row < p.Skv) z = *reinterpret_cast<const u32x4_t*>(Vp + (size_t)(kv0 + row) * p.v_rs + ch * EPC);
       rv[i] = z;
     }
@@ -191,10 +197,12 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs p) {
       for (int e = 0; e < 16; ++e) {
         const float pe = __builtin_amdgcn_exp2f(fmaf(s[sub][e], sc, -m_new));
         s[sub][e] = pe;
-        rs += pe;
+        if (!ONES) rs += pe;
       }
-    rs += __shfl_xor(rs, 32, 64);
-    l_run = fmaf(l_run, alpha, rs);
+    if (!ONES) {
+      rs += __shfl_xor(rs, 32, 64);
+      l_run = fmaf(l_run, alpha, rs);
+    }
     m_run = m_new;
     if (!__all(alpha == 1.0f)) {  // exact: skip the O rescale when no row of this wave got a new max
 #pragma unroll
@@ -251,7 +259,9 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs p) {
 
   // epilogue: O[q][d] = O^T[d][q] / l ; lane holds d = 32i + 8*(e>>2) + 4h + (e&3)
   if (qrow < p.Sq) {
-    const float inv = 1.0f / l_run;
+    float l = l_run;
+    if (ONES) l = __shfl(o[L_BLK][L_REG], r + 32 * L_HALF, 64);   // O^T[D][q] sits in the lane of half L_HALF
+    const float inv = 1.0f / l;
     T* op = (T*)p.O + (size_t)b * p.o_bs + (size_t)qrow * p.o_rs + (size_t)head * D;
 #pragma unroll
     for (int i = 0; i < NB; ++i) {

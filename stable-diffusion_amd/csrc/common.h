@@ -21,7 +21,10 @@ __device__ __forceinline__ bf16_t f2bf(float f) {
   return __builtin_bit_cast(bf16_t, b);
 }
 __device__ __forceinline__ unsigned pack_bf2(float lo, float hi) {
-  return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
+  typedef __attribute__((ext_vector_type(2))) float f32x2_t_;
+  typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t_;
+  const f32x2_t_ v = {lo, hi};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t_));  // one v_cvt_pk_bf16_f32
 }
 
 template <typename T> struct Cvt;
