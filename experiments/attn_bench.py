@@ -7,6 +7,9 @@ torch.set_grad_enabled(False)
 dev = "cuda"
 g = torch.Generator(device=dev).manual_seed(0)
 rnd = lambda *s: torch.randn(*s, device=dev, generator=g).bfloat16()
+import sys as _s
+from sd_amd import _lib
+_lib.lib().sdamd_set_gemm_impl((int(_s.argv[1]) if len(_s.argv) > 1 else 0) << 8)
 shapes = [(16, 8, 40, 4096, 4096), (16, 8, 80, 1024, 1024), (16, 8, 160, 256, 256), (16, 8, 40, 4096, 77), (16, 8, 80, 1024, 77), (16, 8, 160, 256, 77), (16, 8, 160, 64, 64)]
 for B, H, d, Sq, Skv in shapes:
     C = H * d

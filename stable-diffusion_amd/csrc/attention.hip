@@ -20,7 +20,8 @@ struct AttnArgs {
   int H, Sq, Skv;
   long long q_bs, k_bs, v_bs, o_bs;  // batch strides, elements
   int q_rs, k_rs, v_rs, o_rs;        // token strides, elements; head h starts at column h*D
-  float scale_log2e;                 // log2(e) / sqrt(D)
+  float scale_log2e;  // log2(e) / sqrt(D)
+  int debug;          // timing ablations only (experiments/attn_bench.py): 1 no softmax, 2 no PV, 3 no QK, 4 no staging, 5 no barrier
   int causal;
 };
 
@@ -46,6 +47,10 @@ template <int D> struct AttnCfg<float, D> {
   static constexpr int STAGE = BKV * (KS + VS);
 };
 
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+constexpr float RESCALE_THR = 8.0f;
+
+// (forcing 4 waves/SIMD through __launch_bounds__ spills 8-27 registers and measured slower)
 template <typename T, int D>
 __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs p) {
   typedef AttnCfg<T, D> Cfg;
@@ -86,46 +91,61 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs p) {
       if (d0 < D) z = *reinterpret_cast<const u32x4_t*>(qr + d0);
       qf[s] = z;
     }
+    // Launder the fragments through a VALU move: otherwise hipcc's waitcnt pass carries "Q load may
+    // still be outstanding" around the loop back edge and puts s_waitcnt vmcnt(0) in front of the
+    // first MFMAs of every K/V tile -- which also waits for the K/V prefetch issued just before.
+#pragma unroll
+    for (int s = 0; s < NQ; ++s)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) asm volatile("v_mov_b32 %0, %1" : "=v"(qf[s][j]) : "v"(qf[s][j]));
   }
 
-  // register-staged K/V tile: loads for tile t+1 are issued before tile t is computed and
-  // written to the other LDS stage afterwards (pad columns and rows >= Skv are zero-filled)
-  u32x4_t rk[KPT], rv[VPT];
+  // Register-staged K/V tile: the loads of tile t+1 are issued before tile t is computed and written
+  // to the other LDS stage afterwards.  Only the D real columns travel; the pad columns of both
+  // stages (zeros, and the ones column of V) are constant and written once, below.  Rows past Skv
+  // are clamped to the last valid row: their scores are masked, so they only have to be finite.
+  constexpr int KCH2 = BKV * DC;                       // real 16-byte chunks per K (or V) tile
+  constexpr int PT = (KCH2 + 255) / 256;
+  u32x4_t rk[PT], rv[PT];
   auto issue = [&](int kv0) {
 #pragma unroll
-    for (int i = 0; i < KPT; ++i) {
+    for (int i = 0; i < PT; ++i) {
       const int c = t + 256 * i;
-      const int row = c / KC, ch = c - row * KC;
-      u32x4_t z = {0u, 0u, 0u, 0u};
-      if (c < KCH && ch < DC && kv0 + row < p.Skv) z = *reinterpret_cast<const u32x4_t*>(Kp + (size_t)(kv0 + row) * p.k_rs + ch * EPC);
-      rk[i] = z;
-    }
-#pragma unroll
-    for (int i = 0; i < VPT; ++i) {
-      const int c = t + 256 * i;
-      const int row = c / VC, ch = c - row * VC;
-      u32x4_t z = {0u, 0u, 0u, 0u};
-      if (ONES && ch == DC) z[0] = BF ? 0x00003F80u : 0x3F800000u;   // V[:, D] = 1: O^T row D accumulates the row sums
-      if (c < VCH && ch < DC && kv0 + row < p.Skv) z = *reinterpret_cast<const u32x4_t*>(Vp + (size_t)(kv0 + row) * p.v_rs + ch * EPC);
-      rv[i] = z;
+      if (KCH2 % 256 == 0 || c < KCH2) {
+        const int row = c / DC, ch = c - row * DC;
+        const size_t grow = (size_t)min(kv0 + row, p.Skv - 1);
+        rk[i] = *reinterpret_cast<const u32x4_t*>(Kp + grow * p.k_rs + ch * EPC);
+        rv[i] = *reinterpret_cast<const u32x4_t*>(Vp + grow * p.v_rs + ch * EPC);
+      }
     }
   };
   auto commit = [&](int stage) {
     char* ks = smem + stage * STAGE;
     char* vs = ks + BKV * KS;
 #pragma unroll
-    for (int i = 0; i < KPT; ++i) {
+    for (int i = 0; i < PT; ++i) {
       const int c = t + 256 * i;
-      const int row = c / KC, ch = c - row * KC;
-      if (c < KCH) *reinterpret_cast<u32x4_t*>(ks + row * KS + ch * 16) = rk[i];
-    }
-#pragma unroll
-    for (int i = 0; i < VPT; ++i) {
-      const int c = t + 256 * i;
-      const int row = c / VC, ch = c - row * VC;
-      if (c < VCH) *reinterpret_cast<u32x4_t*>(vs + row * VS + ch * 16) = rv[i];
+      if (KCH2 % 256 == 0 || c < KCH2) {
+        const int row = c / DC, ch = c - row * DC;
+        *reinterpret_cast<u32x4_t*>(ks + row * KS + ch * 16) = rk[i];
+        *reinterpret_cast<u32x4_t*>(vs + row * VS + ch * 16) = rv[i];
+      }
     }
   };
+  for (int c = t; c < 2 * BKV * (KC - DC + VC - DC); c += 256) {   // constant pad chunks of both stages
+    constexpr int NPAD = KC - DC + VC - DC;
+    const int srow = c / NPAD, pc = c - srow * NPAD;               // srow = stage * BKV + row
+    char* base = smem + (srow / BKV) * STAGE;
+    const int row = srow % BKV;
+    u32x4_t z = {0u, 0u, 0u, 0u};
+    if (pc < KC - DC) {
+      *reinterpret_cast<u32x4_t*>(base + row * KS + (DC + pc) * 16) = z;
+    } else {
+      const int ch = DC + pc - (KC - DC);
+      if (ONES && ch == DC) z[0] = BF ? 0x00003F80u : 0x3F800000u;   // V[:, D] = 1: O^T row D accumulates the row sums
+      *reinterpret_cast<u32x4_t*>(base + BKV * KS + row * VS + ch * 16) = z;
+    }
+  }
 
   f32x16_t o[NB];
 #pragma unroll
@@ -147,12 +167,15 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs p) {
     const int kv0 = kt * BKV;
     const char* ks = smem + (kt & 1) * STAGE;
     const char* vs = ks + BKV * KS;
-    if (kt + 1 < ntiles) issue(kv0 + BKV);
+    if (kt + 1 < ntiles && p.debug != 4 && p.debug != 5) issue(kv0 + BKV);
 
-    // S^T = K Q^T : rows = keys (accumulator registers), cols = queries (lanes)
+    // Per 32-key sub-tile: S^T = K Q^T (rows = keys in the accumulator registers, cols = queries on
+    // the lanes) -> online softmax (log2 domain) -> O^T += V^T P^T.  Program order is
+    //   QK(0) QK(1) softmax(0) PV(0) softmax(1) PV(1)
+    // so that within one wave the VALU work of a sub-tile is issued while the MFMAs of its neighbour
+    // are still executing (a wave issues in order; MFMA runs asynchronously to VALU).
     f32x16_t s[NSUB];
-#pragma unroll
-    for (int sub = 0; sub < NSUB; ++sub) {
+    auto qk = [&](int sub) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) s[sub][e] = 0.f;
       if constexpr (BF) {
@@ -170,55 +193,54 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs p) {
           for (int e = 0; e < 4; ++e) s[sub] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[e], qv[e], s[sub], 0, 0, 0);
         }
       }
-    }
-
-    // mask (boundary / causal tiles only; wave-uniform branch) + online softmax in the log2 domain
-    if (kv0 + BKV > p.Skv || p.causal) {
-#pragma unroll
-      for (int sub = 0; sub < NSUB; ++sub)
+    };
+    const bool need_mask = kv0 + BKV > p.Skv || p.causal;   // boundary / causal tiles only (wave-uniform)
+    auto softmax = [&](int sub) {
+      if (need_mask) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
           const int key = kv0 + sub * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
           if (key >= p.Skv || (p.causal && key > qrow)) s[sub][e] = -1.0e30f;
         }
-    }
-    float mx = -1.0e30f;
-#pragma unroll
-    for (int sub = 0; sub < NSUB; ++sub)
+      }
+      float mx = -1.0e30f;
 #pragma unroll
       for (int e = 0; e < 16; ++e) mx = fmaxf(mx, s[sub][e]);
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx * sc);
-    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-    float rs = 0.f;
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      // Lazy running max: the reference point m only moves when a row's maximum outgrows it by more
+      // than RESCALE_THR (log2 units), so P stays <= 2^THR and the O rescale below is rare.  Exact in
+      // exact arithmetic (numerator and denominator carry the same factor); P is a float either way.
+      const float mxs = mx * sc;
+      const float m_new = mxs > m_run + RESCALE_THR ? mxs : m_run;
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      float rs = 0.f;
+      const f32x2_t sc2 = {sc, sc}, nm2 = {-m_new, -m_new};
 #pragma unroll
-    for (int sub = 0; sub < NSUB; ++sub)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const float pe = __builtin_amdgcn_exp2f(fmaf(s[sub][e], sc, -m_new));
-        s[sub][e] = pe;
-        if (!ONES) rs += pe;
+      for (int e = 0; e < 16; e += 2) {
+        const f32x2_t a = (f32x2_t){s[sub][e], s[sub][e + 1]} * sc2 + nm2;   // v_pk_fma_f32
+        const float p0 = __builtin_amdgcn_exp2f(a[0]), p1 = __builtin_amdgcn_exp2f(a[1]);
+        s[sub][e] = p0;
+        s[sub][e + 1] = p1;
+        if (!ONES) rs += p0 + p1;
       }
-    if (!ONES) {
-      rs += __shfl_xor(rs, 32, 64);
-      l_run = fmaf(l_run, alpha, rs);
-    }
-    m_run = m_new;
-    if (!__all(alpha == 1.0f)) {  // exact: skip the O rescale when no row of this wave got a new max
+      if (!ONES) {
+        rs += __shfl_xor(rs, 32, 64);
+        l_run = fmaf(l_run, alpha, rs);
+      }
+      m_run = m_new;
+      if (!__all(alpha == 1.0f)) {  // exact: skip the O rescale when no row of this wave moved its reference
 #pragma unroll
-      for (int i = 0; i < NB; ++i)
+        for (int i = 0; i < NB; ++i)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) o[i][e] *= alpha;
-    }
-
-    // O^T += V^T P^T
-    if constexpr (BF) {
-      // transpose read: lane 4q+p of each 16-lane group addresses row q, columns 4p..4p+3 of a
-      // 4-key x 16-column block; element j of the A fragment is key 16*st + 8*(j>>2) + 4h + (j&3)
-      const int g16 = lane >> 4, li = lane & 15;
-      const char* vbase = vs + (4 * (g16 >> 1) + (li >> 2)) * VS + (16 * (g16 & 1) + 4 * (li & 3)) * 2;
-#pragma unroll
-      for (int sub = 0; sub < NSUB; ++sub) {
+          for (int e = 0; e < 16; ++e) o[i][e] *= alpha;
+      }
+    };
+    auto pv = [&](int sub) {   // O^T += V^T P^T
+      if constexpr (BF) {
+        // transpose read: lane 4q+p of each 16-lane group addresses row q, columns 4p..4p+3 of a
+        // 4-key x 16-column block; element j of the A fragment is key 16*st + 8*(j>>2) + 4h + (j&3)
+        const int g16 = lane >> 4, li = lane & 15;
+        const char* vbase = vs + (4 * (g16 >> 1) + (li >> 2)) * VS + (16 * (g16 & 1) + 4 * (li & 3)) * 2;
         bf16x8_t pf[2];
 #pragma unroll
         for (int st = 0; st < 2; ++st) {
@@ -238,10 +260,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs p) {
             o[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, vv), pf[st], o[i], 0, 0, 0);
           }
         }
-      }
-    } else {
-#pragma unroll
-      for (int sub = 0; sub < NSUB; ++sub)
+      } else {
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
 #pragma unroll
@@ -251,10 +270,18 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs p) {
             o[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, s[sub][e], o[i], 0, 0, 0);
           }
         }
+      }
+    };
+#pragma unroll
+    for (int sub = 0; sub < NSUB; ++sub) if (p.debug != 3) qk(sub);
+#pragma unroll
+    for (int sub = 0; sub < NSUB; ++sub) {
+      if (p.debug != 1) softmax(sub);
+      if (p.debug != 2) pv(sub);
     }
 
-    if (kt + 1 < ntiles) commit((kt + 1) & 1);
-    __syncthreads();
+    if (kt + 1 < ntiles && p.debug != 4 && p.debug != 5) commit((kt + 1) & 1);
+    if (p.debug != 5) __syncthreads();
   }
 
   // epilogue: O[q][d] = O^T[d][q] / l ; lane holds d = 32i + 8*(e>>2) + 4h + (e&3)
@@ -316,6 +343,7 @@ extern "C" int sdamd_attention(const void* q, const void* k, const void* v, void
   a.q_rs = q_rs; a.k_rs = k_rs; a.v_rs = v_rs; a.o_rs = o_rs;
   a.scale_log2e = 1.4426950408889634f / sqrtf((float)d);
   a.causal = causal;
+  { extern int g_gemm_debug; a.debug = g_gemm_debug; }
   hipStream_t st = (hipStream_t)stream;
 #define ATT(TT) switch (d) { case 40: return launch_attn<TT, 40>(a, B, st); case 64: return launch_attn<TT, 64>(a, B, st); \
                              case 80: return launch_attn<TT, 80>(a, B, st); default: return launch_attn<TT, 160>(a, B, st); }
