@@ -27,6 +27,9 @@ extern "C" {
 #define SDAMD_ACT_NONE 0
 #define SDAMD_ACT_QUICK_GELU 1 /* x*sigmoid(1.702x), clip.py:67 */
 #define SDAMD_ACT_SILU 2       /* diffusion.py:163 */
+#define SDAMD_ACT_GEGLU 3      /* diffusion.py:128-130 fused into linear_geglu_1: W rows packed so that
+                                * 16-row tile 2c = value channels [16c,16c+16), tile 2c+1 = their gates;
+                                * C is [M][N/2] = value * gelu_erf(gate); bf16, N % 256 == 0, no residual */
 
 const char* sdamd_last_error(void);
 int sdamd_abi_version(void);
@@ -110,6 +113,8 @@ int sdamd_gemm(const void* A, const void* W, void* C, const float* bias, const v
 /* block tile the GEMM/conv launcher picks for a problem (BM*1000+BN + 1000000*(splits-1)); host-only helper
  * used by bench.py to attribute launches to kernel instantiations (no reference counterpart) */
 int sdamd_gemm_tile(int M, int N, int K, int batch, int dtype, size_t ws_bytes);
+/* 1 when sdamd_gemm can apply `act` in its epilogue for this dtype / N (GEGLU: see above) */
+int sdamd_gemm_supports_act(int act, int dtype, int N);
 /* kernel family switch for tests/benchmarks: 0 = auto (8-wave LDS-DMA bf16 kernels where they fit,
  * else the 4-wave register-staged ones), 1 = 4-wave kernels only, 2 = 8-wave kernels whenever
  * one of their tiles divides N, 3 = as 2 with a 3-way K split (small-size parity tests);

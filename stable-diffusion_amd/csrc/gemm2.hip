@@ -244,7 +244,49 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm2_kernel(const GemmArgs p) 
   __syncthreads();  // every wave is done reading the last K-tile (and no DMA is outstanding)
   const float* __restrict__ bias = p.bias;
   const int mw = m0 + wm * WTM, nw = n0 + wn * WTN;  // this wave's sub-tile origin
-  if (p.out_f32) {
+  if (p.act == ACT_GEGLU) {
+    // GeGLU epilogue (diffusion.py:128-130): the weight rows were packed so that 16-column tile 2c
+    // holds the value channels [16c, 16c+16) and tile 2c+1 their gates; value * gelu_erf(gate) is
+    // lane-local on the f32 accumulators and only the N/2 products are rounded and stored (bf16).
+    if constexpr (TN % 2 == 0) {
+      constexpr int WTO = WTN / 2;                         // output columns of this wave
+      constexpr int RS = WTO * 2 + 16;
+      constexpr int IPMAX = (STAGES * STAGE / NW) / (16 * RS);
+      constexpr int IP = IPMAX >= TM ? TM : (IPMAX >= TM / 2 && TM % 2 == 0) ? TM / 2 : (IPMAX >= TM / 4 && TM % 4 == 0) ? TM / 4 : 1;
+      static_assert(IPMAX >= 1, "epilogue staging does not fit");
+      constexpr int CPR = WTO / 8;
+      char* const slice = smem + wave * (IP * 16 * RS);
+      bf16_t* __restrict__ C = (bf16_t*)p.C + (size_t)batch * p.sC;
+      const int nwo = (n0 >> 1) + wn * WTO;                // first output column of this wave
+#pragma unroll
+      for (int ps = 0; ps < TM / IP; ++ps) {
+#pragma unroll
+        for (int ii = 0; ii < IP; ++ii) {
+#pragma unroll
+          for (int j = 0; j < TN; j += 2) {
+            f32x4_t v = acc[j][ps * IP + ii], g = acc[j + 1][ps * IP + ii];
+            const int n = nw + j * 16 + q4 * 4;
+            if (bias && n + 16 < p.N) {
+              v += *reinterpret_cast<const f32x4_t*>(bias + n);
+              g += *reinterpret_cast<const f32x4_t*>(bias + n + 16);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] *= gelu_erf_f(g[r]);
+            const u32x2_t o = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+            *reinterpret_cast<u32x2_t*>(slice + (ii * 16 + r16) * RS + ((j >> 1) * 16 + q4 * 4) * 2) = o;
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (int idx = lane; idx < IP * 16 * CPR; idx += 64) {
+          const int row = idx / CPR, ch = idx - row * CPR;
+          const int m = mw + ps * IP * 16 + row, n = nwo + ch * 8;
+          const u32x4_t v = *reinterpret_cast<const u32x4_t*>(slice + row * RS + ch * 16);
+          if (m < p.M && n < (p.N >> 1)) *reinterpret_cast<u32x4_t*>(C + (size_t)m * p.ldc + n) = v;
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+  } else if (p.out_f32) {
     constexpr int RS = WTN * 4 + 16;                     // padded LDS row stride (bytes)
     constexpr int IPMAX = (STAGES * STAGE / NW) / (16 * RS);  // 16-row tiles per pass that fit the wave's slice
     constexpr int IP = IPMAX >= TM ? TM : (IPMAX >= TM / 2 && TM % 2 == 0) ? TM / 2 : (IPMAX >= TM / 4 && TM % 4 == 0) ? TM / 4 : 1;
@@ -429,7 +471,12 @@ int gemm2_choose_tile(int M, int N, int K, int batch, int mode, size_t ws_bytes,
 int launch_gemm2_bf16(GemmArgs& a, int batch, bool conv, int mode, hipStream_t st) {
   if ((a.ldr % 4) != 0 || (a.R && ((uintptr_t)a.R % 16) != 0)) return -1;
   if (!a.out_f32 && ((a.ldc % 8) != 0 || (a.sC % 8) != 0)) return -1;   // 16-byte row-segment stores
-  const int tile = gemm2_choose_tile(a.M, a.N, a.K, batch, mode, a.ws ? a.ws_bytes : 0, &a.splits);
+  int tile = gemm2_choose_tile(a.M, a.N, a.K, batch, mode, a.ws ? a.ws_bytes : 0, &a.splits);
+  if (a.act == ACT_GEGLU) {   // needs an even number of 16-column tiles per wave: the 256x256 tile
+    if (conv || a.out_f32 || a.R || a.N % 256 != 0) return -1;
+    tile = 256256;
+    a.splits = 1;
+  }
   switch (tile) {
     case 256160: return conv ? launch2<256, 160, 4, 2, 3, true>(a, batch, st) : launch2<256, 160, 4, 2, 3, false>(a, batch, st);
     case 128160: return conv ? launch2<128, 160, 2, 2, 2, true>(a, batch, st) : launch2<128, 160, 2, 2, 2, false>(a, batch, st);

@@ -5,6 +5,7 @@
 #define ACT_NONE 0
 #define ACT_QUICK_GELU 1
 #define ACT_SILU 2
+#define ACT_GEGLU 3   // column tiles alternate value | gate (16 wide): out[m][c] = value * gelu_erf(gate), N/2 columns
 
 struct GemmArgs {
   const void* A;     // dense: [M][lda]; conv: NHWC input [B][H][W][Cin]

@@ -357,6 +357,12 @@ static int g_gemm_impl = 0;
 int g_gemm_debug = 0;
 extern "C" int sdamd_set_gemm_impl(int impl) { int old = g_gemm_impl; g_gemm_impl = impl & 255; g_gemm_debug = impl >> 8; return old; }
 
+// 1 when sdamd_gemm can run `act` fused for this dtype / N with the current kernel family selection
+extern "C" int sdamd_gemm_supports_act(int act, int dtype, int N) {
+  if (act != ACT_GEGLU) return act >= ACT_NONE && act <= ACT_SILU;
+  return dtype == SDAMD_BF16 && g_gemm_impl != 1 && N % 256 == 0;
+}
+
 extern "C" int sdamd_gemm_tile(int M, int N, int K, int batch, int dtype, size_t ws_bytes) {
   if (dtype == SDAMD_BF16 && g_gemm_impl != 1) {
     int splits = 1;
@@ -399,7 +405,7 @@ extern "C" int sdamd_gemm(const void* A, const void* W, void* C, const float* bi
   a.act = act; a.out_f32 = out_f32;
   if (int e = check_common(a, dtype, "gemm")) return e;
   const int esz = dtype == SDAMD_BF16 ? 2 : 4;
-  SD_CHECK((lda * esz) % 16 == 0 && lda >= K && ldw >= K && ldc >= N, "gemm: bad leading dimensions lda=%d ldw=%d ldc=%d", lda, ldw, ldc);
+  SD_CHECK((lda * esz) % 16 == 0 && lda >= K && ldw >= K && ldc >= (act == ACT_GEGLU ? N / 2 : N), "gemm: bad leading dimensions lda=%d ldw=%d ldc=%d", lda, ldw, ldc);
   SD_CHECK(batch >= 1, "gemm: batch=%d", batch);
   SD_CHECK(!residual || (ldr >= N && ldr % 4 == 0 && ((uintptr_t)residual % 16) == 0), "gemm: residual needs ldr=%d >= N, ldr %% 4 == 0 and 16-byte alignment", ldr);
   hipStream_t st = (hipStream_t)stream;
@@ -407,6 +413,7 @@ extern "C" int sdamd_gemm(const void* A, const void* W, void* C, const float* bi
     const int r = launch_gemm2_bf16(a, batch, false, g_gemm_impl, st);
     if (r >= 0) return r;
   }
+  SD_CHECK(act != ACT_GEGLU, "gemm: the fused GeGLU epilogue needs bf16, N %% 256 == 0, no residual, bf16 output and the 8-wave kernels");
   if (dtype == SDAMD_BF16) return pick_tile<bf16_t, false>(a, batch, st);
   return pick_tile<float, false>(a, batch, st);
 }

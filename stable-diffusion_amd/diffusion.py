@@ -89,7 +89,7 @@ class UNET_AttentionBlock(engine.HipModule):
                            out_dtype=td).view(B, H * W, C)
         t = engine.self_attention(engine.layernorm(t, self.layernorm_1, dt), self.attention_1, residual=t)
         t = engine.cross_attention(engine.layernorm(t, self.layernorm_2, dt), self.attention_2, kv, residual=t)
-        g = ops.geglu(engine.linear(engine.layernorm(t, self.layernorm_3, dt), self.linear_geglu_1))
+        g = engine.linear_geglu(engine.layernorm(t, self.layernorm_3, dt), self.linear_geglu_1)
         t = engine.linear(g, self.linear_geglu_2, residual=t)
         return engine.conv1x1(t.view(B, H, W, C), self.conv_output, residual=x, compute_dtype=dt)
 

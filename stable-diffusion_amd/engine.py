@@ -117,6 +117,17 @@ def linear(x, lin, residual=None, act=ops.ACT_NONE, out_dtype=None):
     return ops.gemm(x, linear_w(lin, x.dtype), bias_of(lin), residual, act, _out_f32(x, residual, out_dtype))
 
 
+def linear_geglu(x, lin):
+    """diffusion.py:127-130: x, gate = linear_geglu_1(x).chunk(2, -1); x * gelu(gate) -- as one GEMM
+    whose epilogue gates the f32 accumulators when the kernel family supports it (bf16), else the
+    GEMM followed by the GeGLU kernel."""
+    if ops.gemm_supports_act(ops.ACT_GEGLU, x.dtype, lin.out_features):
+        w = packed(lin.weight, "geglu_w", x.dtype, lambda t: ops.geglu_pack(t.to(x.dtype)))
+        b = packed(lin.bias, "geglu_b", torch.float32, lambda t: ops.geglu_pack(t.float()))
+        return ops.gemm(x, w, b, None, ops.ACT_GEGLU)
+    return ops.geglu(linear(x, lin))
+
+
 def conv1x1(x, conv, residual=None, out_dtype=None, compute_dtype=None):
     """x NHWC [B,H,W,C].  An f32 ``x`` under a bf16 compute dtype is the residual trunk itself:
     it goes through the MFMA as two bf16 terms (hi|lo) against [W|W] instead of being rounded."""

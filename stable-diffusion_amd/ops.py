@@ -13,7 +13,7 @@ import torch
 from . import _lib
 
 F32, BF16 = 0, 1
-ACT_NONE, ACT_QUICK_GELU, ACT_SILU = 0, 1, 2
+ACT_NONE, ACT_QUICK_GELU, ACT_SILU, ACT_GEGLU = 0, 1, 2, 3
 
 
 def _code(dtype):
@@ -372,21 +372,35 @@ def gemm(a, w, bias=None, residual=None, act=ACT_NONE, out_f32=False):
         assert a.is_contiguous(), "gemm: batched inputs must be contiguous"
         lda = K
     out_dtype = torch.float32 if out_f32 else a.dtype
-    out = torch.empty(lead + (N,), dtype=out_dtype, device=a.device)
+    n_out = N // 2 if act == ACT_GEGLU else N     # GEGLU: w rows are value|gate tiles, see geglu_pack
+    out = torch.empty(lead + (n_out,), dtype=out_dtype, device=a.device)
     ldr = 0
     if residual is not None:
-        assert residual.dtype == out_dtype and residual.is_contiguous() and residual.numel() == M * N, \
+        assert residual.dtype == out_dtype and residual.is_contiguous() and residual.numel() == M * n_out, \
             (residual.dtype, out_dtype, residual.shape, M, N)
         ldr = N
     if bias is not None:
         assert bias.dtype == torch.float32 and bias.numel() == N and bias.is_contiguous()
     ws = _gemm_workspace(a.device)
     _timed(f"gemm_{_dt(a.dtype)}_{_tile_tag(M, N, K, a.dtype, ws)}" if PROFILER is not None else "", 2.0 * M * N * K,
-           lambda: _lib.check(_lib.lib().sdamd_gemm(_p(a), _p(w), _p(out), _p(bias), _p(residual), M, N, K, lda, K, N, ldr, 1,
+           lambda: _lib.check(_lib.lib().sdamd_gemm(_p(a), _p(w), _p(out), _p(bias), _p(residual), M, N, K, lda, K, n_out, ldr, 1,
                                                     0, 0, 0, 0, int(act), _code(a.dtype), int(out_f32), _p(ws), ws.numel(),
                                                     _stream())),
-           f"M{M} N{N} K{K}{' +res' if residual is not None else ''}{' f32out' if out_f32 else ''}")
+           f"M{M} N{N} K{K}{' +res' if residual is not None else ''}{' f32out' if out_f32 else ''}{' geglu' if act == ACT_GEGLU else ''}")
     return out
+
+
+def gemm_supports_act(act, dtype, N):
+    return bool(_lib.lib().sdamd_gemm_supports_act(int(act), _code(dtype), int(N)))
+
+
+def geglu_pack(t):
+    """[2F, ...] (value rows, then gate rows; diffusion.py:128 chunk(2)) -> rows interleaved in
+    16-row tiles value|gate, the layout ACT_GEGLU expects of W and bias."""
+    F2 = t.shape[0]
+    v, g = t[:F2 // 2], t[F2 // 2:]
+    tail = t.shape[1:]
+    return torch.stack([v.reshape((F2 // 32, 16) + tail), g.reshape((F2 // 32, 16) + tail)], 1).reshape(t.shape).contiguous()
 
 
 def bmm_nt(a, b, out_f32=False):

@@ -259,6 +259,25 @@ def test_gemm(dtype, M, N, K, bias, res, act, gemm_impl):
         assert got32.dtype == torch.float32 and rel_l2(got32.cpu(), want) < 2e-5
 
 
+@pytest.mark.parametrize("M,C", [(300, 320), (4096, 640), (77, 1280)])
+def test_gemm_fused_geglu(M, C):
+    """linear_geglu_1 + GeGLU as one launch (value|gate tile-interleaved weights) vs torch on the
+    same bf16 operands; one rounding of the product instead of two."""
+    dtype = torch.bfloat16
+    assert ops.gemm_supports_act(ops.ACT_GEGLU, dtype, 8 * C) and not ops.gemm_supports_act(ops.ACT_GEGLU, torch.float32, 8 * C)
+    a = q(rnd(f"gg.a.{M}", (M, C)), dtype)
+    w = q(rnd(f"gg.w.{C}", (8 * C, C), 1.0 / math.sqrt(C)), dtype)
+    b = rnd(f"gg.b.{C}", (8 * C,))
+    y = a.double() @ w.double().t() + b.double()
+    val, gate = y.float().chunk(2, dim=-1)
+    want = val * F.gelu(gate)
+    got = ops.gemm(a.to(dtype).to(DEV), ops.geglu_pack(w.to(dtype)).to(DEV), ops.geglu_pack(b).to(DEV), None, ops.ACT_GEGLU)
+    assert tuple(got.shape) == (M, 4 * C) and got.dtype == dtype
+    assert rel_l2(got.float().cpu(), want) < 4e-3
+    unfused = ops.geglu(ops.gemm(a.to(dtype).to(DEV), w.to(dtype).to(DEV), b.to(DEV)))
+    assert rel_l2(got.float().cpu(), want) <= rel_l2(unfused.float().cpu(), want) * 1.05
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_gemm_strided_views_and_batched(dtype, gemm_impl):
     qkv = q(rnd("bmm.qkv", (2, 192, 3 * 512)), dtype)
