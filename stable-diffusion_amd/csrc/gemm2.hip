@@ -452,13 +452,20 @@ int gemm2_choose_tile(int M, int N, int K, int batch, int mode, size_t ws_bytes,
   }
   extern int g_gemm_debug;
   if (g_gemm_debug == 4 && N % 160 == 0 && blocks(256, 160) >= 256) return 256160;   // experiment: 3-stage ring
+  if (g_gemm_debug >= 32) {   // experiment: forced tile / split (debug = 32 + 8*tile + splits)
+    static const int tiles[4] = {128160, 128320, 256256, 256160};
+    const int s = (g_gemm_debug - 32) & 7;
+    if (s >= 1 && s <= max_splits() && s <= nk) *splits = s;
+    return tiles[((g_gemm_debug - 32) >> 3) & 3];
+  }
   if (N % 320 == 0 && blocks(128, 320) >= 256) return 128320;
   if (N % 160 == 0) {
+    // 4-wave tile, two workgroups per CU: aim at >= 512 workgroups, splitting K up to 4 ways while
+    // every split keeps >= 16 K-tiles (measured: 16x16 maps S=2 607->832 TF, 8x8 maps S=4 174->484 TF)
     const long long b = blocks(128, 160);
-    if (b >= 192) return 128160;
-    int s = (int)((256 + b - 1) / b);
-    if (s > 8) s = 8;
-    if (s > nk / 4) s = nk / 4;
+    int s = (int)((512 + b - 1) / b);
+    if (s > 4) s = 4;
+    if (s > nk / 16) s = nk / 16;
     if (s > max_splits()) s = max_splits();
     if (s >= 2) { *splits = s; return 128160; }
     if (b >= 128) return 128160;
