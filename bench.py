@@ -109,12 +109,44 @@ def roofline_leg(models, args, device):
                      "frac": round(rate / (PEAK[dt] if mfma else PEAK["hbm"]), 4)})
     rows.sort(key=lambda r: -r["total_ms"])
     top = rows[0]
-    roof = {"kernel": top["kernel"], "bound": top["bound"], "achieved": top["achieved"],
+    work = summ[top["kernel"]]["work"] / top["launches"]
+    roof = {"kernel": top["kernel"], "symbol": kernel_symbol(top["kernel"]), "bound": top["bound"],
+            "achieved": top["achieved"],
             "peak": PEAK["bf16" if "_bf16" in top["kernel"] else "f32"] if top["bound"] == "mfma" else PEAK["hbm"],
-            "unit": top["unit"], "frac": top["frac"], "traffic": None,
+            "unit": top["unit"], "frac": top["frac"], "traffic": pmc_traffic(kernel_symbol(top["kernel"])),
             "launches": top["launches"], "avg_launch_us": top["avg_us"],
-            "note": "algorithmic FLOPs of every launch of this kernel family in one bench step / summed HIP-event time"}
+            "algorithmic_work_per_launch": round(work / (1e9 if top["bound"] == "mfma" else 1e6), 3),
+            "work_unit": "GFLOP" if top["bound"] == "mfma" else "MB",
+            "note": "dominant kernel instantiation of one bench step (most summed time): mean algorithmic FLOPs per launch / "
+                    "mean launch duration, HIP events on the launch stream in one extra eager pass; traffic = mean HBM bytes "
+                    "per launch from profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                    "command, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950), null if not collected"}
     return roof, rows
+
+
+def kernel_symbol(kind):
+    """Bench label -> substring of the kernel's demangled name in a rocprofv3 trace."""
+    parts = kind.split("_")
+    if parts[0] in ("gemm", "conv3x3") and len(parts) >= 3 and "x" in parts[2]:
+        bm, bn = parts[2].split("x")
+        conv = "true" if parts[0] == "conv3x3" else "false"
+        if parts[1] == "bf16" and (bm, bn) in (("128", "320"), ("128", "160"), ("256", "256"), ("256", "160")):
+            wg = {"128x320": "2, 4, 2", "128x160": "2, 2, 2", "256x256": "2, 4, 2", "256x160": "4, 2, 3"}[parts[2]]
+            return f"gemm2_kernel<{bm}, {bn}, {wg}, {conv}>"
+        t = "unsigned short" if parts[1] == "bf16" else "float"
+        return f"gemm_kernel<{t}, {bm}, {bn}, {conv}>"
+    if parts[0] == "attention":
+        t = "unsigned short" if parts[1] == "bf16" else "float"
+        return f"attn_kernel<{t}, {parts[2][1:]}>"
+    return kind
+
+
+def pmc_traffic(symbol):
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if not os.path.exists(path):
+        return None
+    ent = json.load(open(path)).get(symbol)
+    return None if ent is None else ent["hbm_bytes_per_launch"]
 
 
 def cpu_baseline_leg(cpu_sd):

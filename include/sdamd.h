@@ -112,7 +112,7 @@ int sdamd_gemm(const void* A, const void* W, void* C, const float* bias, const v
                int out_f32, void* ws, size_t ws_bytes, void* stream);
 /* block tile the GEMM/conv launcher picks for a problem (BM*1000+BN + 1000000*(splits-1)); host-only helper
  * used by bench.py to attribute launches to kernel instantiations (no reference counterpart) */
-int sdamd_gemm_tile(int M, int N, int K, int batch, int dtype, size_t ws_bytes);
+int sdamd_gemm_tile(int M, int N, int K, int batch, int dtype, size_t ws_bytes, int act);
 /* 1 when sdamd_gemm can apply `act` in its epilogue for this dtype / N (GEGLU: see above) */
 int sdamd_gemm_supports_act(int act, int dtype, int N);
 /* kernel family switch for tests/benchmarks: 0 = auto (8-wave LDS-DMA bf16 kernels where they fit,

@@ -363,9 +363,10 @@ extern "C" int sdamd_gemm_supports_act(int act, int dtype, int N) {
   return dtype == SDAMD_BF16 && g_gemm_impl != 1 && N % 256 == 0;
 }
 
-extern "C" int sdamd_gemm_tile(int M, int N, int K, int batch, int dtype, size_t ws_bytes) {
+extern "C" int sdamd_gemm_tile(int M, int N, int K, int batch, int dtype, size_t ws_bytes, int act) {
   if (dtype == SDAMD_BF16 && g_gemm_impl != 1) {
     int splits = 1;
+    if (act == ACT_GEGLU) return 256256;
     if (int t2 = gemm2_choose_tile(M, N, K, batch, g_gemm_impl, ws_bytes, &splits)) return t2 + 1000000 * (splits - 1);
   }
   return choose_tile(M, N, batch);

@@ -83,8 +83,8 @@ def _timed(kind, work, launch, shape=""):
     return r
 
 
-def _tile_tag(M, N, K, dtype, ws, batch=1):
-    t = _lib.lib().sdamd_gemm_tile(M, N, K, batch, _code(dtype), ws.numel())
+def _tile_tag(M, N, K, dtype, ws, batch=1, act=0):
+    t = _lib.lib().sdamd_gemm_tile(M, N, K, batch, _code(dtype), ws.numel(), int(act))
     t, s = t % 1000000, t // 1000000 + 1
     return f"{t // 1000}x{t % 1000}" + (f"_splitk{s}" if s > 1 else "")
 
@@ -382,7 +382,7 @@ def gemm(a, w, bias=None, residual=None, act=ACT_NONE, out_f32=False):
     if bias is not None:
         assert bias.dtype == torch.float32 and bias.numel() == N and bias.is_contiguous()
     ws = _gemm_workspace(a.device)
-    _timed(f"gemm_{_dt(a.dtype)}_{_tile_tag(M, N, K, a.dtype, ws)}" if PROFILER is not None else "", 2.0 * M * N * K,
+    _timed(f"gemm_{_dt(a.dtype)}_{_tile_tag(M, N, K, a.dtype, ws, 1, act)}" if PROFILER is not None else "", 2.0 * M * N * K,
            lambda: _lib.check(_lib.lib().sdamd_gemm(_p(a), _p(w), _p(out), _p(bias), _p(residual), M, N, K, lda, K, n_out, ldr, 1,
                                                     0, 0, 0, 0, int(act), _code(a.dtype), int(out_f32), _p(ws), ws.numel(),
                                                     _stream())),

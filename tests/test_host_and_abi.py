@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(handle, name), name
     assert _lib.lib().sdamd_abi_version() == 2
-    assert _lib.lib().sdamd_gemm_tile(65536, 320, 320, 1, 0, 0) == 128064
+    assert _lib.lib().sdamd_gemm_tile(65536, 320, 320, 1, 0, 0, 0) == 128064
 
 
 def test_product_schedules_match_reference_bit_exactly():
