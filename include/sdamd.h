@@ -123,7 +123,10 @@ int sdamd_set_gemm_impl(int impl);
 /* ---- implicit-GEMM conv3x3 over NHWC: nn.Conv2d(k=3) of diffusion.py:9,13,146,204-221,
  * decoder.py:10-13,92-111, encoder.py:13-45.  w [Cout][ky][kx][Cin]; pad_mode 0 = pad 1,
  * 1 = bottom/right pad only (encoder.py:65-66); upsample=1 fuses F.interpolate(nearest,2x)
- * (diffusion.py:148-150, decoder.py:90); residual [B][Ho][Wo][Cout] or null. */
+ * (diffusion.py:148-150, decoder.py:90) into the gather; upsample=2 computes the same result as
+ * four 2x2 convs, one per output phase (py,px), at 4/9 of the MACs: w is then
+ * [4][Cout][2][2][Cin] with the 3x3 taps that read the same input pixel summed (bf16 only);
+ * residual [B][Ho][Wo][Cout] or null. */
 int sdamd_conv3x3(const void* x, const void* w, void* y, const float* bias, const void* residual,
                   int B, int H, int W, int Cin, int Cout, int stride, int pad_mode, int upsample,
                   int act, int dtype, int out_f32, void* ws, size_t ws_bytes, void* stream);

@@ -68,6 +68,20 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm2_kernel(const GemmArgs p) 
   const int batch = blockIdx.y;   // (split-K launches have batch == 1 and use blockIdx.z = split)
   const bf16_t* __restrict__ A = (const bf16_t*)p.A + (size_t)batch * p.sA;
   const bf16_t* __restrict__ W = (const bf16_t*)p.W + (size_t)batch * p.sW;
+  // Phase-decomposed upsample conv (CONV, p.phase_up): "batch" is the output phase (py, px).  Output
+  // pixel (2y+py, 2x+px) of conv3x3(nearest2x(in)) only sees the 2x2 input window starting at
+  // (y-(1-py), x-(1-px)), with the 3x3 taps that land on the same input pixel pre-summed on the host:
+  // 4/9 of the MACs.  Rows m index the LOW-resolution grid; out_row() maps them to the output.
+  const bool phase_up = CONV && p.phase_up;
+  const int py = phase_up ? (batch >> 1) : 0, px = phase_up ? (batch & 1) : 0;
+  const int ntx = phase_up ? 2 : 3;                       // taps per filter row
+  auto out_row = [&](int m) -> size_t {
+    if (!phase_up) return (size_t)m;
+    const int hw = p.Ho * p.Wo;
+    const int n_img = m / hw, rem = m - n_img * hw;
+    const int y = rem / p.Wo, x = rem - y * p.Wo;
+    return ((size_t)n_img * 2 * p.Ho + 2 * y + py) * (2 * p.Wo) + 2 * x + px;
+  };
 
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -93,8 +107,8 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm2_kernel(const GemmArgs p) 
       const int hw = p.Ho * p.Wo;
       const int n_img = m / hw, rem = m - n_img * hw;
       const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
-      ay[i] = oy * p.stride - p.pad;
-      ax[i] = ox * p.stride - p.pad;
+      ay[i] = oy * p.stride - (phase_up ? 1 - py : p.pad);
+      ax[i] = ox * p.stride - (phase_up ? 1 - px : p.pad);
       asrc[i] = A + (size_t)n_img * p.H * p.Wd * p.Cin + coff;
     } else {
       asrc[i] = A + (size_t)m * p.lda + coff;
@@ -136,7 +150,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm2_kernel(const GemmArgs p) 
   auto stage_tile = [&](char* stage, int k0) {   // all pieces back to back (prologue)
     if (p.debug == 1) return;
     int ky = 0, kx = 0;
-    if (CONV) { ky = tap / 3; kx = tap - ky * 3; }
+    if (CONV) { ky = tap / ntx; kx = tap - ky * ntx; }
     [&]<int... PI>(std::integer_sequence<int, PI...>) { (stage_piece(std::integral_constant<int, PI>{}, stage, k0, ky, kx), ...); }
     (std::make_integer_sequence<int, NPIECE>{});
     advance_k();
@@ -158,7 +172,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm2_kernel(const GemmArgs p) 
     const char* sa = stage;
     const char* sw = stage + BM * 128;
     int ky = 0, kx = 0;
-    if (CONV) { ky = tap / 3; kx = tap - ky * 3; }
+    if (CONV) { ky = tap / ntx; kx = tap - ky * ntx; }
     if (p.debug == 1) do_stage = false;
     constexpr int NGROUP = 2 * TN;
 #pragma unroll
@@ -281,7 +295,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm2_kernel(const GemmArgs p) 
           const int row = idx / CPR, ch = idx - row * CPR;
           const int m = mw + ps * IP * 16 + row, n = nwo + ch * 8;
           const u32x4_t v = *reinterpret_cast<const u32x4_t*>(slice + row * RS + ch * 16);
-          if (m < p.M && n < (p.N >> 1)) *reinterpret_cast<u32x4_t*>(C + (size_t)m * p.ldc + n) = v;
+          if (m < p.M && n < (p.N >> 1)) *reinterpret_cast<u32x4_t*>(C + out_row(m) * p.ldc + n) = v;
         }
         __builtin_amdgcn_wave_barrier();
       }
@@ -313,7 +327,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm2_kernel(const GemmArgs p) 
         const int m = mw + ps * IP * 16 + row, n = nw + ch * 4;
         f32x4_t v = *reinterpret_cast<const f32x4_t*>(slice + row * RS + ch * 16);
         if (m < p.M && n < p.N) {
-          if (Rf) v += *reinterpret_cast<const f32x4_t*>(Rf + (size_t)m * p.ldr + n);
+          if (Rf) v += *reinterpret_cast<const f32x4_t*>(Rf + out_row(m) * p.ldr + n);
           if (p.act == ACT_QUICK_GELU) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = quick_gelu_f(v[r]);
@@ -321,7 +335,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm2_kernel(const GemmArgs p) 
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = silu_f(v[r]);
           }
-          *reinterpret_cast<f32x4_t*>(C + (size_t)m * p.ldc + n) = v;
+          *reinterpret_cast<f32x4_t*>(C + out_row(m) * p.ldc + n) = v;
         }
       }
       __builtin_amdgcn_wave_barrier();
@@ -346,7 +360,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm2_kernel(const GemmArgs p) 
           const int n = nw + j * 16 + q4 * 4;
           if (bias && n < p.N) v += *reinterpret_cast<const f32x4_t*>(bias + n);
           if (R && m < p.M && n < p.N) {   // (bf16 residual trunks are the rare case: added before rounding)
-            const u32x2_t rv = *reinterpret_cast<const u32x2_t*>(R + (size_t)m * p.ldr + n);
+            const u32x2_t rv = *reinterpret_cast<const u32x2_t*>(R + out_row(m) * p.ldr + n);
             v[0] += __builtin_bit_cast(float, rv[0] << 16); v[1] += __builtin_bit_cast(float, rv[0] & 0xffff0000u);
             v[2] += __builtin_bit_cast(float, rv[1] << 16); v[3] += __builtin_bit_cast(float, rv[1] & 0xffff0000u);
           }
@@ -366,7 +380,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm2_kernel(const GemmArgs p) 
         const int row = idx / CPR, ch = idx - row * CPR;
         const int m = mw + ps * IP * 16 + row, n = nw + ch * 8;
         const u32x4_t v = *reinterpret_cast<const u32x4_t*>(slice + row * RS + ch * 16);
-        if (m < p.M && n < p.N) *reinterpret_cast<u32x4_t*>(C + (size_t)m * p.ldc + n) = v;
+        if (m < p.M && n < p.N) *reinterpret_cast<u32x4_t*>(C + out_row(m) * p.ldc + n) = v;
       }
       __builtin_amdgcn_wave_barrier();
     }

@@ -19,6 +19,7 @@ struct GemmArgs {
   int act, out_f32;
   // conv geometry (CONV only)
   int H, Wd, Cin, Ho, Wo, stride, pad, ups;
+  int phase_up;  // 1: nearest-2x upsample + conv3x3 as four 2x2 convs, grid.y = output phase (py, px); see sdamd_conv3x3
   int tiles_m, tiles_n;
   // split-K (gemm2.hip): grid.z = splits, each writes raw f32 partials to ws[split][M][N]
   int splits;

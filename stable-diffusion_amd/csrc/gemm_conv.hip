@@ -427,8 +427,29 @@ extern "C" int sdamd_conv3x3(const void* x, const void* w, void* y, const float*
                              int out_f32, void* ws, size_t ws_bytes, void* stream) {
   SD_CHECK(stride == 1 || stride == 2, "conv3x3: stride=%d", stride);
   SD_CHECK(pad_mode == 0 || pad_mode == 1, "conv3x3: pad_mode=%d", pad_mode);
-  SD_CHECK(upsample == 0 || upsample == 1, "conv3x3: upsample=%d", upsample);
+  SD_CHECK(upsample >= 0 && upsample <= 2, "conv3x3: upsample=%d", upsample);
   SD_CHECK(B > 0 && H > 0 && Wd > 0, "conv3x3: empty input");
+  hipStream_t st = (hipStream_t)stream;
+  if (upsample == 2) {
+    // nearest-2x upsample + conv3x3 (pad 1, stride 1) as four 2x2 convs, one per output phase:
+    // w is [4 phases (py,px)][Cout][2][2][Cin] with the coinciding 3x3 taps pre-summed (engine.py)
+    SD_CHECK(dtype == SDAMD_BF16 && g_gemm_impl != 1 && stride == 1 && pad_mode == 0 && !residual,
+             "conv3x3: the phase-decomposed upsample form needs bf16, the 8-wave kernels, stride 1, pad 1, no residual");
+    SD_CHECK(Cin % 64 == 0, "conv3x3: Cin=%d must be a multiple of 64", Cin);
+    GemmArgs a = {};
+    a.A = x; a.W = w; a.C = y; a.bias = bias; a.R = nullptr;
+    a.M = B * H * Wd; a.N = Cout; a.K = 4 * Cin;
+    a.lda = 0; a.ldw = 4 * Cin; a.ldc = Cout; a.ldr = Cout;
+    a.sA = 0; a.sW = (long long)Cout * 4 * Cin; a.sC = 0; a.sR = 0;
+    a.act = act; a.out_f32 = out_f32;
+    a.splits = 1; a.ws = nullptr; a.ws_bytes = 0; a.debug = g_gemm_debug;
+    a.H = H; a.Wd = Wd; a.Cin = Cin; a.Ho = H; a.Wo = Wd; a.stride = 1; a.pad = 1; a.ups = 0; a.phase_up = 1;
+    if (int e = check_common(a, dtype, "conv3x3")) return e;
+    int r = launch_gemm2_bf16(a, 4, true, g_gemm_impl, st);
+    if (r < 0) r = launch_gemm2_bf16(a, 4, true, 2, st);   // few workgroups: any tile that divides Cout
+    SD_CHECK(r >= 0, "conv3x3: no 8-wave tile divides Cout=%d", Cout);
+    return r;
+  }
   const int Hin = H << upsample, Win = Wd << upsample;
   const int pad = pad_mode == 0 ? 1 : 0;
   const int Ho = pad_mode == 0 ? (Hin + 2 - 3) / stride + 1 : (Hin + 1 - 3) / stride + 1;
@@ -443,7 +464,6 @@ extern "C" int sdamd_conv3x3(const void* x, const void* w, void* y, const float*
   if (int e = check_common(a, dtype, "conv3x3")) return e;
   const int bke = dtype == SDAMD_BF16 ? 64 : 32;
   SD_CHECK(Cin % bke == 0, "conv3x3: Cin=%d must be a multiple of %d (use the small-channel kernels)", Cin, bke);
-  hipStream_t st = (hipStream_t)stream;
   if (dtype == SDAMD_BF16 && g_gemm_impl != 1) {
     const int r = launch_gemm2_bf16(a, 1, true, g_gemm_impl, st);
     if (r >= 0) return r;

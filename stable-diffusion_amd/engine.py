@@ -140,8 +140,32 @@ def conv1x1(x, conv, residual=None, out_dtype=None, compute_dtype=None):
 
 
 def conv3x3(x, conv, residual=None, stride=1, pad_mode=0, upsample=False, bias=None, out_dtype=None):
+    if upsample and residual is None and stride == 1 and pad_mode == 0 and x.dtype == torch.bfloat16 and \
+            ops.gemm_supports_act(ops.ACT_GEGLU, torch.bfloat16, 256) and \
+            (conv.out_channels % 160 == 0 or conv.out_channels % 256 == 0):
+        # nearest-2x + conv3x3 as four 2x2 phase convs (4/9 of the MACs), see conv3x3_up_phase_w
+        return ops.conv3x3(x, conv3x3_up_phase_w(conv, x.dtype, 1), bias_of(conv) if bias is None else bias, None, 1, 0, 2,
+                           out_f32=_out_f32(x, residual, out_dtype))
     return ops.conv3x3(x, conv3x3_w(conv, x.dtype), bias_of(conv) if bias is None else bias, residual, stride,
                        pad_mode, upsample, out_f32=_out_f32(x, residual, out_dtype))
+
+
+def conv3x3_up_phase_w(conv, dtype, dup):
+    """OIHW -> [4 phases (py,px)][O][2][2][dup*I]: nearest-2x upsample + conv3x3(pad 1) restated as
+    one 2x2 conv per output phase.  Output row 2y+py reads input rows {y-1: k0, y: k1+k2} (py=0) or
+    {y: k0+k1, y+1: k2} (py=1); same along x.  The tap sums are formed in f32, then rounded."""
+    def build(w):
+        w = w.float()
+        rows = (torch.stack([w[:, :, 0], w[:, :, 1] + w[:, :, 2]], 2), torch.stack([w[:, :, 0] + w[:, :, 1], w[:, :, 2]], 2))
+        out = []
+        for py in range(2):
+            r = rows[py]                                           # [O, I, 2, 3]
+            cols = (torch.stack([r[..., 0], r[..., 1] + r[..., 2]], 3), torch.stack([r[..., 0] + r[..., 1], r[..., 2]], 3))
+            for px in range(2):
+                k = cols[px].permute(0, 2, 3, 1)                   # [O, 2, 2, I]
+                out.append(k.repeat(1, 1, 1, dup).reshape(k.shape[0], -1))
+        return torch.stack(out).to(dtype).contiguous()
+    return packed(conv.weight, f"c3up{dup}", dtype, build)
 
 
 def conv3x3_trunk(x, conv, compute_dtype, stride=1, upsample=False):
@@ -149,6 +173,10 @@ def conv3x3_trunk(x, conv, compute_dtype, stride=1, upsample=False):
     x's dtype; an f32 trunk under bf16 compute goes through the MFMA as [hi|lo] channels against
     [W|W] per tap (see conv1x1)."""
     if compute_dtype == torch.bfloat16 and x.dtype == torch.float32:
+        if upsample and ops.gemm_supports_act(ops.ACT_GEGLU, torch.bfloat16, 256) and \
+                (conv.out_channels % 160 == 0 or conv.out_channels % 256 == 0):   # an 8-wave tile divides Cout
+            return ops.conv3x3(ops.split_hilo(x), conv3x3_up_phase_w(conv, torch.bfloat16, 2), bias_of(conv), None, 1, 0, 2,
+                               out_f32=True)
         w2 = packed(conv.weight, "c3x2", torch.bfloat16,
                     lambda w: w.permute(0, 2, 3, 1).to(torch.bfloat16).repeat(1, 1, 1, 2).reshape(w.shape[0], -1).contiguous())
         return ops.conv3x3(ops.split_hilo(x), w2, bias_of(conv), None, stride, 0, upsample, out_f32=True)

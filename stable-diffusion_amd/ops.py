@@ -422,7 +422,12 @@ def conv3x3(x, w, bias, residual=None, stride=1, pad_mode=0, upsample=False, act
     assert x.is_contiguous() and x.dim() == 4 and w.is_contiguous() and w.dtype == x.dtype
     B, H, W, Cin = x.shape
     Cout = w.shape[0]
-    assert w.shape[1] == 9 * Cin, (w.shape, Cin)
+    upsample = int(upsample)           # 0 | 1 (gathered nearest-2x) | 2 (phase-decomposed, w [4][Cout][4*Cin])
+    if upsample == 2:
+        assert w.dim() == 3 and w.shape[0] == 4 and w.shape[2] == 4 * Cin and stride == 1 and pad_mode == 0 and residual is None
+        Cout = w.shape[1]
+    else:
+        assert w.shape[1] == 9 * Cin, (w.shape, Cin)
     Hin, Win = (H * 2, W * 2) if upsample else (H, W)
     if pad_mode == 0:
         Ho, Wo = (Hin + 2 - 3) // stride + 1, (Win + 2 - 3) // stride + 1
@@ -435,9 +440,9 @@ def conv3x3(x, w, bias, residual=None, stride=1, pad_mode=0, upsample=False, act
         assert bias.dtype == torch.float32 and bias.numel() == Cout
     M = B * Ho * Wo
     ws = _gemm_workspace(x.device)
-    _timed(f"conv3x3_{_dt(x.dtype)}_{_tile_tag(M, Cout, 9 * Cin, x.dtype, ws)}" if PROFILER is not None else "", 2.0 * M * Cout * 9 * Cin,
+    _timed(f"conv3x3_{_dt(x.dtype)}_{_tile_tag(M, Cout, 9 * Cin, x.dtype, ws)}" if PROFILER is not None else "", 2.0 * M * Cout * 9 * Cin,   # algorithmic (reference) FLOPs, also for the 4/9-MAC phase form
            lambda: _lib.check(_lib.lib().sdamd_conv3x3(_p(x), _p(w), _p(out), _p(bias), _p(residual), B, H, W, Cin, Cout, stride,
-                                                       pad_mode, int(upsample), int(act), _code(x.dtype), int(out_f32),
+                                                       pad_mode, upsample, int(act), _code(x.dtype), int(out_f32),
                                                        _p(ws), ws.numel(), _stream())),
            f"M{M} N{Cout} K{9 * Cin} s{stride}{' up' if upsample else ''}{' +res' if residual is not None else ''}{' f32out' if out_f32 else ''}")
     return out

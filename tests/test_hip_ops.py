@@ -316,6 +316,24 @@ def test_conv3x3(dtype, B, Cin, Cout, H, W, stride, pad_mode, ups, res, gemm_imp
     assert rel_l2(from_nhwc(got), want.float()) < tol(dtype, 2e-6, 4e-3)
 
 
+@pytest.mark.parametrize("B,C,Cout,H,W,dup", [(2, 64, 320, 8, 8, 1), (1, 128, 160, 5, 7, 1), (2, 64, 320, 4, 4, 2)])
+def test_conv3x3_upsample_phase_form(B, C, Cout, H, W, dup):
+    """nearest-2x + conv3x3 as four 2x2 phase convs (4/9 of the MACs) == the gathered form."""
+    from sd_amd import engine
+    conv = torch.nn.Conv2d(C, Cout, 3, padding=1)
+    synth.load_hashed(conv, f"ops.upphase{C}.")
+    x = rnd(f"upphase.x.{C}.{H}", (B, C, H, W))
+    want = conv(F.interpolate(x, scale_factor=2, mode="nearest"))
+    conv.to(DEV)
+    wp = engine.conv3x3_up_phase_w(conv, torch.bfloat16, dup)
+    assert tuple(wp.shape) == (4, Cout, 4 * dup * C)
+    xin = to_nhwc(x, torch.float32)
+    xin = ops.split_hilo(xin) if dup == 2 else xin.bfloat16()
+    got = ops.conv3x3(xin, wp, engine.f32(conv.bias), None, 1, 0, 2, out_f32=True)
+    assert tuple(got.shape) == (B, 2 * H, 2 * W, Cout)
+    assert rel_l2(from_nhwc(got), want) < (2e-3 if dup == 2 else 4e-3)
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_small_channel_convs(dtype):
     from sd_amd import engine
