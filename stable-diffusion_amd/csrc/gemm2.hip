@@ -437,12 +437,15 @@ static int launch2(GemmArgs& a, int batch, hipStream_t st) {
   dim3 grid(a.tiles_m * a.tiles_n, batch, a.splits);
   gemm2_kernel<BM, BN, WGM, WGN, STAGES, CONV><<<grid, WGM * WGN * 64, lds, st>>>(a);
   SD_LAUNCH_CHECK("gemm2");
-  if (a.splits > 1) {
-    size_t items = (size_t)a.M * (a.N >> 2);
-    int g = (int)((items + 255) / 256 > 2048 ? 2048 : (items + 255) / 256);
-    splitk_reduce_kernel<<<g, 256, 0, st>>>(a);
-    SD_LAUNCH_CHECK("splitk_reduce");
-  }
+  if (a.splits > 1) return launch_splitk_reduce(a, st);
+  return 0;
+}
+
+int launch_splitk_reduce(const GemmArgs& a, hipStream_t st) {
+  size_t items = (size_t)a.M * (a.N >> 2);
+  int g = (int)((items + 255) / 256 > 2048 ? 2048 : (items + 255) / 256);
+  splitk_reduce_kernel<<<g, 256, 0, st>>>(a);
+  SD_LAUNCH_CHECK("splitk_reduce");
   return 0;
 }
 

@@ -33,3 +33,6 @@ struct GemmArgs {
 // family fits the problem (the caller then uses the 4-wave register-staged kernels), 0 on launch.
 int launch_gemm2_bf16(GemmArgs& a, int batch, bool conv, int mode, hipStream_t st);   // mode: g_gemm_impl
 int gemm2_choose_tile(int M, int N, int K, int batch, int mode, size_t ws_bytes, int* splits);
+
+// out = act(sum_s ws[s] + bias + residual) for a split-K launch (gemm2.hip)
+int launch_splitk_reduce(const GemmArgs& a, hipStream_t st);

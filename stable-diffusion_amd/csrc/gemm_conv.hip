@@ -93,8 +93,14 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
   }
   const int Hin = p.H << p.ups, Win = p.Wd << p.ups;
 
+  // split-K (grid.z): this workgroup's K-tiles are [kt_begin, kt_begin + nk)
+  const int nk_total = p.K / BKE;
+  const int split = blockIdx.z;
+  const int kt_begin = (int)((long long)nk_total * split / p.splits);
+  const int nk = (int)((long long)nk_total * (split + 1) / p.splits) - kt_begin;
   u32x4_t ra[PA], rw[PW];
   int tap = 0, cc = 0;  // conv K position: filter tap and channel offset
+  if (CONV) { const int kpt = p.Cin / BKE; tap = kt_begin / kpt; cc = (kt_begin - tap * kpt) * BKE; }
   auto issue_loads = [&](int k0) {
 #pragma unroll
     for (int i = 0; i < PW; ++i) rw[i] = *reinterpret_cast<const u32x4_t*>(wptr[i] + k0);
@@ -128,14 +134,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
 #pragma unroll
     for (int i = 0; i < TM; ++i) acc[j][i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
-  const int nk = p.K / BKE;
-  issue_loads(0);
+  issue_loads(kt_begin * BKE);
   write_lds(0);
   __syncthreads();
   const int r16 = lane & 15, q4 = lane >> 4;
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
-    if (kt + 1 < nk) issue_loads((kt + 1) * BKE);
+    if (kt + 1 < nk) issue_loads((kt_begin + kt + 1) * BKE);
     const char* sa = smem + cur * STAGE;
     const char* sw = sa + BM * 128;
 #pragma unroll
@@ -154,6 +159,21 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
     }
     if (kt + 1 < nk) write_lds(cur ^ 1);
     __syncthreads();
+  }
+
+  if (p.splits > 1) {  // raw f32 partial sums; splitk_reduce_kernel (gemm2.hip) applies the epilogue
+    float* __restrict__ ws = p.ws + (size_t)split * p.M * p.N;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int m = m0 + wm * (BM / 2) + i * 16 + r16;
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * (BN / 2) + j * 16 + q4 * 4;
+        if (n < p.N) *reinterpret_cast<f32x4_t*>(ws + (size_t)m * p.N + n) = acc[j][i];
+      }
+    }
+    return;
   }
 
   // epilogue: lane holds out[m][n..n+3]
@@ -332,9 +352,27 @@ static int launch_gemm(GemmArgs& a, int batch, hipStream_t st) {
     (void)hipFuncSetAttribute((const void*)gemm_kernel<T, BM, BN, CONV>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_set = true;
   }
-  dim3 grid(a.tiles_m * a.tiles_n, batch);
+  // split-K for the parallelism-starved shapes (fp32 UNet at batch 2: M = 128 .. 2048 with K up to
+  // 23040 leaves most CUs idle): aim at >= 512 workgroups, keep >= 8 K-tiles per split
+  a.splits = 1;
+  const long long blocks = (long long)a.tiles_m * a.tiles_n * batch;
+  const int nk = a.K / (int)(128 / sizeof(T));
+  const size_t slab = (size_t)a.M * a.N * sizeof(float);
+  if (batch == 1 && a.ws && blocks < 256 && nk >= 16 && a.ldr % 4 == 0 && a.ldc % 4 == 0) {
+    long long s = (512 + blocks - 1) / blocks;
+    if (s > 8) s = 8;
+    if (s > nk / 8) s = nk / 8;
+    if (s * slab > a.ws_bytes) s = (long long)(a.ws_bytes / slab);
+    if (s >= 2) a.splits = (int)s;
+  }
+  dim3 grid(a.tiles_m * a.tiles_n, batch, a.splits);
   gemm_kernel<T, BM, BN, CONV><<<grid, 256, lds, st>>>(a);
   SD_LAUNCH_CHECK("gemm");
+  if (a.splits > 1) {
+    GemmArgs r = a;
+    if (sizeof(T) == 4) r.out_f32 = 1;   // f32 operands: C and the residual are f32
+    return launch_splitk_reduce(r, st);
+  }
   return 0;
 }
 
