@@ -41,8 +41,11 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int BM, int BN, int WGM, int WGN, int STAGES, bool CONV>
+template <typename T, int BM, int BN, int WGM, int WGN, int STAGES, bool CONV>
 __global__ __launch_bounds__(WGM* WGN * 64) void gemm2_kernel(const GemmArgs p) {
+  constexpr bool F32 = sizeof(T) == 4;     // exact-f32 MFMA (v_mfma_f32_16x16x4_f32) on f32 operands
+  constexpr int EPC = 16 / sizeof(T);      // elements per 16-byte chunk
+  constexpr int BKE = 8 * EPC;             // K elements per 128-byte tile row (64 bf16 / 32 f32)
   constexpr int NW = WGM * WGN;
   constexpr int WTM = BM / WGM, WTN = BN / WGN;  // per-wave output tile
   constexpr int TM = WTM / 16, TN = WTN / 16;    // 16x16 MFMA tiles per wave
@@ -66,8 +69,8 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm2_kernel(const GemmArgs p) 
   const int tn = bid % p.tiles_n, tm = bid / p.tiles_n;
   const int m0 = tm * BM, n0 = tn * BN;
   const int batch = blockIdx.y;   // (split-K launches have batch == 1 and use blockIdx.z = split)
-  const bf16_t* __restrict__ A = (const bf16_t*)p.A + (size_t)batch * p.sA;
-  const bf16_t* __restrict__ W = (const bf16_t*)p.W + (size_t)batch * p.sW;
+  const T* __restrict__ A = (const T*)p.A + (size_t)batch * p.sA;
+  const T* __restrict__ W = (const T*)p.W + (size_t)batch * p.sW;
   // Phase-decomposed upsample conv (CONV, p.phase_up): "batch" is the output phase (py, px).  Output
   // pixel (2y+py, 2x+px) of conv3x3(nearest2x(in)) only sees the 2x2 input window starting at
   // (y-(1-py), x-(1-px)), with the 3x3 taps that land on the same input pixel pre-summed on the host:
@@ -89,20 +92,20 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm2_kernel(const GemmArgs p) 
   const int rr = lane >> 3, cl = lane & 7;
 
   // per-lane DMA sources: piece i of this wave covers tile rows (wave + NW*i)*8 .. +7
-  const bf16_t* wsrc[B_INS];
+  const T* wsrc[B_INS];
 #pragma unroll
   for (int i = 0; i < B_INS; ++i) {
     const int row = min(wave + NW * i, B_PIECES - 1) * 8 + rr;
     const int n = min(n0 + row, p.N - 1);
-    wsrc[i] = W + (size_t)n * p.ldw + ((cl ^ ((row >> 1) & 7)) << 3);
+    wsrc[i] = W + (size_t)n * p.ldw + (cl ^ ((row >> 1) & 7)) * EPC;
   }
-  const bf16_t* asrc[A_INS];  // dense: row pointer (+ swizzled chunk); conv: image base (+ chunk)
+  const T* asrc[A_INS];  // dense: row pointer (+ swizzled chunk); conv: image base (+ chunk)
   int ay[A_INS], ax[A_INS];   // conv: top-left input coordinate of the 3x3 window (upsampled grid)
 #pragma unroll
   for (int i = 0; i < A_INS; ++i) {
     const int row = min(wave + NW * i, A_PIECES - 1) * 8 + rr;
     const int m = min(m0 + row, p.M - 1);
-    const int coff = (cl ^ ((row >> 1) & 7)) << 3;
+    const int coff = (cl ^ ((row >> 1) & 7)) * EPC;
     if (CONV) {
       const int hw = p.Ho * p.Wo;
       const int n_img = m / hw, rem = m - n_img * hw;
@@ -116,22 +119,22 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm2_kernel(const GemmArgs p) 
     }
   }
   const int Hin = p.H << p.ups, Win = p.Wd << p.ups;
-  const bf16_t* zsrc = reinterpret_cast<const bf16_t*>(g_zero_page) + (cl << 3);
+  const T* zsrc = reinterpret_cast<const T*>(g_zero_page) + cl * EPC;
 
   // this workgroup's K-tiles: [kt_begin, kt_begin + nk)
-  const int nk_total = p.K >> 6;
+  const int nk_total = p.K / BKE;
   const int split = blockIdx.z;
   const int kt_begin = (int)((long long)nk_total * split / p.splits);
   const int nk = (int)((long long)nk_total * (split + 1) / p.splits) - kt_begin;
   int tap = 0, cc = 0;  // conv K position of the next tile to stage: filter tap, channel offset
-  if (CONV) { const int kpt = p.Cin >> 6; tap = kt_begin / kpt; cc = (kt_begin - tap * kpt) << 6; }
+  if (CONV) { const int kpt = p.Cin / BKE; tap = kt_begin / kpt; cc = (kt_begin - tap * kpt) * BKE; }
   // DMA piece PI (compile-time) of the tile at K offset k0 / conv position (ky, kx, cc)
   auto stage_piece = [&](auto PIC, char* stage, int k0, int ky, int kx) {
     constexpr int PI = decltype(PIC)::value;
     if constexpr (PI < A_INS) {
       constexpr int i = PI;
       if (A_PIECES % NW != 0 && i == A_INS - 1 && wave + NW * i >= A_PIECES) return;
-      const bf16_t* g;
+      const T* g;
       if (CONV) {
         const int iy = ay[i] + ky, ix = ax[i] + kx;
         const bool ok = (unsigned)iy < (unsigned)Hin && (unsigned)ix < (unsigned)Win;
@@ -146,7 +149,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm2_kernel(const GemmArgs p) 
       __builtin_amdgcn_global_load_lds((gbl_void_t*)(wsrc[i] + k0), (lds_void_t*)(stage + BM * 128 + (wave + NW * i) * 1024), 16, 0, 0);
     }
   };
-  auto advance_k = [&]() { if (CONV) { cc += 64; if (cc >= p.Cin) { cc = 0; ++tap; } } };
+  auto advance_k = [&]() { if (CONV) { cc += BKE; if (cc >= p.Cin) { cc = 0; ++tap; } } };
   auto stage_tile = [&](char* stage, int k0) {   // all pieces back to back (prologue)
     if (p.debug == 1) return;
     int ky = 0, kx = 0;
@@ -177,17 +180,27 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm2_kernel(const GemmArgs p) 
     constexpr int NGROUP = 2 * TN;
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
-      bf16x8_t xf[TM], wf[TN];
+      // one 16-byte fragment per lane and tile: 8 bf16 (one 16x16x32 MFMA) or 4 f32 (four 16x16x4
+      // MFMAs; the k order inside the group is permuted alike for both operands)
+      typedef typename std::conditional<F32, f32x4_t, bf16x8_t>::type frag_t;
+      frag_t xf[TM], wf[TN];
 #pragma unroll
-      for (int j = 0; j < TN; ++j) wf[j] = *reinterpret_cast<const bf16x8_t*>(sw + swz2(wn * WTN + j * 16 + r16, 4 * g + q4));
+      for (int j = 0; j < TN; ++j) wf[j] = *reinterpret_cast<const frag_t*>(sw + swz2(wn * WTN + j * 16 + r16, 4 * g + q4));
 #pragma unroll
-      for (int i = 0; i < TM; ++i) xf[i] = *reinterpret_cast<const bf16x8_t*>(sa + swz2(wm * WTM + i * 16 + r16, 4 * g + q4));
+      for (int i = 0; i < TM; ++i) xf[i] = *reinterpret_cast<const frag_t*>(sa + swz2(wm * WTM + i * 16 + r16, 4 * g + q4));
       [&]<int... J>(std::integer_sequence<int, J...>) {
         ([&] {
           constexpr int j = J;
           if (p.debug != 2) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc[j][i], 0, 0, 0);
+            for (int i = 0; i < TM; ++i) {
+              if constexpr (F32) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[j][e], xf[i][e], acc[j][i], 0, 0, 0);
+              } else {
+                acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc[j][i], 0, 0, 0);
+              }
+            }
           }
           // pieces assigned to MFMA group q = g*TN + j: those with PI*NGROUP/NPIECE == q
           [&]<int... PI>(std::integer_sequence<int, PI...>) {
@@ -208,16 +221,16 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm2_kernel(const GemmArgs p) 
     if (kt + STAGES - 1 <= nk) wait_vmcnt<(STAGES - 2) * MIN_PIECES>(); else wait_vmcnt<0>(); \
     __builtin_amdgcn_s_barrier();                                                        \
     if (INTERLEAVE_DMA) {                                                                \
-      compute_tile(smem + (BUF) * STAGE, smem + (NEXTBUF) * STAGE, kt + STAGES - 1 < nk, (kt_begin + kt + STAGES - 1) << 6); \
+      compute_tile(smem + (BUF) * STAGE, smem + (NEXTBUF) * STAGE, kt + STAGES - 1 < nk, (kt_begin + kt + STAGES - 1) * BKE); \
     } else {                                                                             \
-      if (kt + STAGES - 1 < nk) stage_tile(smem + (NEXTBUF) * STAGE, (kt_begin + kt + STAGES - 1) << 6); \
+      if (kt + STAGES - 1 < nk) stage_tile(smem + (NEXTBUF) * STAGE, (kt_begin + kt + STAGES - 1) * BKE); \
       compute_tile(smem + (BUF) * STAGE, nullptr, false, 0);                             \
     }                                                                                    \
     if (++kt >= nk) break;                                                               \
   }
   int kt = 0;
-  stage_tile(smem, kt_begin << 6);
-  if (STAGES == 3 && nk > 1) stage_tile(smem + STAGE, (kt_begin + 1) << 6);
+  stage_tile(smem, kt_begin * BKE);
+  if (STAGES == 3 && nk > 1) stage_tile(smem + STAGE, (kt_begin + 1) * BKE);
   if (STAGES == 2) {
     for (;;) {
       GEMM2_STEP(0, 1)
@@ -258,7 +271,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm2_kernel(const GemmArgs p) 
   __syncthreads();  // every wave is done reading the last K-tile (and no DMA is outstanding)
   const float* __restrict__ bias = p.bias;
   const int mw = m0 + wm * WTM, nw = n0 + wn * WTN;  // this wave's sub-tile origin
-  if (p.act == ACT_GEGLU) {
+  if (!F32 && p.act == ACT_GEGLU) {
     // GeGLU epilogue (diffusion.py:128-130): the weight rows were packed so that 16-column tile 2c
     // holds the value channels [16c, 16c+16) and tile 2c+1 their gates; value * gelu_erf(gate) is
     // lane-local on the f32 accumulators and only the N/2 products are rounded and stored (bf16).
@@ -300,7 +313,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm2_kernel(const GemmArgs p) 
         __builtin_amdgcn_wave_barrier();
       }
     }
-  } else if (p.out_f32) {
+  } else if (F32 || p.out_f32) {
     constexpr int RS = WTN * 4 + 16;                     // padded LDS row stride (bytes)
     constexpr int IPMAX = (STAGES * STAGE / NW) / (16 * RS);  // 16-row tiles per pass that fit the wave's slice
     constexpr int IP = IPMAX >= TM ? TM : (IPMAX >= TM / 2 && TM % 2 == 0) ? TM / 2 : (IPMAX >= TM / 4 && TM % 4 == 0) ? TM / 4 : 1;
@@ -423,21 +436,25 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
   }
 }
 
-template <int BM, int BN, int WGM, int WGN, int STAGES, bool CONV>
+template <typename T, int BM, int BN, int WGM, int WGN, int STAGES, bool CONV>
 static int launch2(GemmArgs& a, int batch, hipStream_t st) {
   a.tiles_m = (a.M + BM - 1) / BM;
   a.tiles_n = (a.N + BN - 1) / BN;
   constexpr int lds = STAGES * (BM + BN) * 128;
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)gemm2_kernel<BM, BN, WGM, WGN, STAGES, CONV>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)gemm2_kernel<T, BM, BN, WGM, WGN, STAGES, CONV>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
       return sdamd_set_error(2, "gemm2: cannot reserve %d bytes of LDS", lds);
     attr_set = true;
   }
   dim3 grid(a.tiles_m * a.tiles_n, batch, a.splits);
-  gemm2_kernel<BM, BN, WGM, WGN, STAGES, CONV><<<grid, WGM * WGN * 64, lds, st>>>(a);
+  gemm2_kernel<T, BM, BN, WGM, WGN, STAGES, CONV><<<grid, WGM * WGN * 64, lds, st>>>(a);
   SD_LAUNCH_CHECK("gemm2");
-  if (a.splits > 1) return launch_splitk_reduce(a, st);
+  if (a.splits > 1) {
+    GemmArgs r = a;
+    if (sizeof(T) == 4) r.out_f32 = 1;   // f32 operands: C and the residual are f32
+    return launch_splitk_reduce(r, st);
+  }
   return 0;
 }
 
@@ -456,9 +473,9 @@ int launch_splitk_reduce(const GemmArgs& a, hipStream_t st) {
 // kernel finishes the epilogue; that needs the caller's workspace.
 // mode: 0 = auto, 2 = any fitting tile however few workgroups, 3 = as 2 plus a 3-way K split.
 // Returns BM*1000+BN (0: use the 4-wave kernels of gemm_conv.hip) and *splits.
-int gemm2_choose_tile(int M, int N, int K, int batch, int mode, size_t ws_bytes, int* splits) {
+int gemm2_choose_tile(int M, int N, int K, int batch, int mode, size_t ws_bytes, int* splits, int bke) {
   auto blocks = [&](int bm, int bn) { return (long long)((M + bm - 1) / bm) * ((N + bn - 1) / bn) * batch; };
-  const int nk = K >> 6;
+  const int nk = K / bke;
   const size_t slab = (size_t)M * N * sizeof(float);
   auto max_splits = [&]() { return (batch == 1 && slab > 0) ? (int)(ws_bytes / slab) : 1; };
   *splits = 1;
@@ -476,6 +493,17 @@ int gemm2_choose_tile(int M, int N, int K, int batch, int mode, size_t ws_bytes,
     return tiles[((g_gemm_debug - 32) >> 3) & 3];
   }
   if (N % 320 == 0 && blocks(128, 320) >= 256) return 128320;
+  if (bke == 32) {
+    // f32 operands (exact 16x16x4 MFMA, ~4x the issue cycles per byte staged): the 8-wave layout only
+    // wins over the register-staged 64-wide tiles once >= 256 workgroups exist (measured at UNet
+    // batch 2: 105-118 TF vs 65-95 TF above that line, 15-57 TF vs 55-85 TF below it)
+    if (N % 160 != 0) return 0;
+    const long long b = blocks(128, 160);
+    int s = (int)((256 + b - 1) / b);
+    if (s > 8 || (s > 1 && s > nk / 16) || s > max_splits()) return 0;
+    *splits = s;
+    return 128160;
+  }
   if (N % 160 == 0) {
     // 4-wave tile, two workgroups per CU: aim at >= 512 workgroups, splitting K up to 4 ways while
     // every split keeps >= 16 K-tiles (measured: 16x16 maps S=2 607->832 TF, 8x8 maps S=4 174->484 TF)
@@ -492,20 +520,26 @@ int gemm2_choose_tile(int M, int N, int K, int batch, int mode, size_t ws_bytes,
   return 0;
 }
 
-int launch_gemm2_bf16(GemmArgs& a, int batch, bool conv, int mode, hipStream_t st) {
+template <typename T>
+static int launch_gemm2_t(GemmArgs& a, int batch, bool conv, int mode, hipStream_t st) {
   if ((a.ldr % 4) != 0 || (a.R && ((uintptr_t)a.R % 16) != 0)) return -1;
-  if (!a.out_f32 && ((a.ldc % 8) != 0 || (a.sC % 8) != 0)) return -1;   // 16-byte row-segment stores
-  int tile = gemm2_choose_tile(a.M, a.N, a.K, batch, mode, a.ws ? a.ws_bytes : 0, &a.splits);
+  if (sizeof(T) == 2 && !a.out_f32 && ((a.ldc % 8) != 0 || (a.sC % 8) != 0)) return -1;   // 16-byte row-segment stores
+  if (sizeof(T) == 4 && ((a.ldc % 4) != 0 || (a.sC % 4) != 0)) return -1;
+  int tile = gemm2_choose_tile(a.M, a.N, a.K, batch, mode, a.ws ? a.ws_bytes : 0, &a.splits, 128 / (int)sizeof(T));
   if (a.act == ACT_GEGLU) {   // needs an even number of 16-column tiles per wave: the 256x256 tile
-    if (conv || a.out_f32 || a.R || a.N % 256 != 0) return -1;
+    if (sizeof(T) == 4 || conv || a.out_f32 || a.R || a.N % 256 != 0) return -1;
     tile = 256256;
     a.splits = 1;
   }
   switch (tile) {
-    case 256160: return conv ? launch2<256, 160, 4, 2, 3, true>(a, batch, st) : launch2<256, 160, 4, 2, 3, false>(a, batch, st);
-    case 128160: return conv ? launch2<128, 160, 2, 2, 2, true>(a, batch, st) : launch2<128, 160, 2, 2, 2, false>(a, batch, st);
-    case 128320: return conv ? launch2<128, 320, 2, 4, 2, true>(a, batch, st) : launch2<128, 320, 2, 4, 2, false>(a, batch, st);
-    case 256256: return conv ? launch2<256, 256, 2, 4, 2, true>(a, batch, st) : launch2<256, 256, 2, 4, 2, false>(a, batch, st);
+    case 256160: return conv ? launch2<T, 256, 160, 4, 2, 3, true>(a, batch, st) : launch2<T, 256, 160, 4, 2, 3, false>(a, batch, st);
+    case 128160: return conv ? launch2<T, 128, 160, 2, 2, 2, true>(a, batch, st) : launch2<T, 128, 160, 2, 2, 2, false>(a, batch, st);
+    case 128320: return conv ? launch2<T, 128, 320, 2, 4, 2, true>(a, batch, st) : launch2<T, 128, 320, 2, 4, 2, false>(a, batch, st);
+    case 256256: return conv ? launch2<T, 256, 256, 2, 4, 2, true>(a, batch, st) : launch2<T, 256, 256, 2, 4, 2, false>(a, batch, st);
     default: a.splits = 1; return -1;
   }
+}
+
+int launch_gemm2(GemmArgs& a, int dtype, int batch, bool conv, int mode, hipStream_t st) {
+  return dtype == SDAMD_BF16 ? launch_gemm2_t<bf16_t>(a, batch, conv, mode, st) : launch_gemm2_t<float>(a, batch, conv, mode, st);
 }

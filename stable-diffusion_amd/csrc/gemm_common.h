@@ -29,10 +29,10 @@ struct GemmArgs {
 };
 
 
-// gemm2.hip: 8-wave, LDS-DMA-staged bf16 kernels.  Returns -1 when no tile configuration of that
+// gemm2.hip: 8-wave, LDS-DMA-staged kernels (bf16 and exact-f32 MFMA).  Returns -1 when no tile configuration of that
 // family fits the problem (the caller then uses the 4-wave register-staged kernels), 0 on launch.
-int launch_gemm2_bf16(GemmArgs& a, int batch, bool conv, int mode, hipStream_t st);   // mode: g_gemm_impl
-int gemm2_choose_tile(int M, int N, int K, int batch, int mode, size_t ws_bytes, int* splits);
+int launch_gemm2(GemmArgs& a, int dtype, int batch, bool conv, int mode, hipStream_t st);   // mode: g_gemm_impl
+int gemm2_choose_tile(int M, int N, int K, int batch, int mode, size_t ws_bytes, int* splits, int bke);
 
 // out = act(sum_s ws[s] + bias + residual) for a split-K launch (gemm2.hip)
 int launch_splitk_reduce(const GemmArgs& a, hipStream_t st);

@@ -402,10 +402,11 @@ extern "C" int sdamd_gemm_supports_act(int act, int dtype, int N) {
 }
 
 extern "C" int sdamd_gemm_tile(int M, int N, int K, int batch, int dtype, size_t ws_bytes, int act) {
-  if (dtype == SDAMD_BF16 && g_gemm_impl != 1) {
+  if (g_gemm_impl != 1) {
     int splits = 1;
-    if (act == ACT_GEGLU) return 256256;
-    if (int t2 = gemm2_choose_tile(M, N, K, batch, g_gemm_impl, ws_bytes, &splits)) return t2 + 1000000 * (splits - 1);
+    if (act == ACT_GEGLU && dtype == SDAMD_BF16) return 256256;
+    if (int t2 = gemm2_choose_tile(M, N, K, batch, g_gemm_impl, ws_bytes, &splits, dtype == SDAMD_BF16 ? 64 : 32))
+      return t2 + 1000000 * (splits - 1);
   }
   return choose_tile(M, N, batch);
 }
@@ -448,8 +449,8 @@ extern "C" int sdamd_gemm(const void* A, const void* W, void* C, const float* bi
   SD_CHECK(batch >= 1, "gemm: batch=%d", batch);
   SD_CHECK(!residual || (ldr >= N && ldr % 4 == 0 && ((uintptr_t)residual % 16) == 0), "gemm: residual needs ldr=%d >= N, ldr %% 4 == 0 and 16-byte alignment", ldr);
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == SDAMD_BF16 && g_gemm_impl != 1) {
-    const int r = launch_gemm2_bf16(a, batch, false, g_gemm_impl, st);
+  if (g_gemm_impl != 1) {
+    const int r = launch_gemm2(a, dtype, batch, false, g_gemm_impl, st);
     if (r >= 0) return r;
   }
   SD_CHECK(act != ACT_GEGLU, "gemm: the fused GeGLU epilogue needs bf16, N %% 256 == 0, no residual, bf16 output and the 8-wave kernels");
@@ -471,9 +472,9 @@ extern "C" int sdamd_conv3x3(const void* x, const void* w, void* y, const float*
   if (upsample == 2) {
     // nearest-2x upsample + conv3x3 (pad 1, stride 1) as four 2x2 convs, one per output phase:
     // w is [4 phases (py,px)][Cout][2][2][Cin] with the coinciding 3x3 taps pre-summed (engine.py)
-    SD_CHECK(dtype == SDAMD_BF16 && g_gemm_impl != 1 && stride == 1 && pad_mode == 0 && !residual,
-             "conv3x3: the phase-decomposed upsample form needs bf16, the 8-wave kernels, stride 1, pad 1, no residual");
-    SD_CHECK(Cin % 64 == 0, "conv3x3: Cin=%d must be a multiple of 64", Cin);
+    SD_CHECK(g_gemm_impl != 1 && stride == 1 && pad_mode == 0 && !residual,
+             "conv3x3: the phase-decomposed upsample form needs the 8-wave kernels, stride 1, pad 1, no residual");
+    SD_CHECK(Cin % (dtype == SDAMD_BF16 ? 64 : 32) == 0, "conv3x3: Cin=%d must be a multiple of the K-tile", Cin);
     GemmArgs a = {};
     a.A = x; a.W = w; a.C = y; a.bias = bias; a.R = nullptr;
     a.M = B * H * Wd; a.N = Cout; a.K = 4 * Cin;
@@ -483,8 +484,8 @@ extern "C" int sdamd_conv3x3(const void* x, const void* w, void* y, const float*
     a.splits = 1; a.ws = nullptr; a.ws_bytes = 0; a.debug = g_gemm_debug;
     a.H = H; a.Wd = Wd; a.Cin = Cin; a.Ho = H; a.Wo = Wd; a.stride = 1; a.pad = 1; a.ups = 0; a.phase_up = 1;
     if (int e = check_common(a, dtype, "conv3x3")) return e;
-    int r = launch_gemm2_bf16(a, 4, true, g_gemm_impl, st);
-    if (r < 0) r = launch_gemm2_bf16(a, 4, true, 2, st);   // few workgroups: any tile that divides Cout
+    int r = launch_gemm2(a, dtype, 4, true, g_gemm_impl, st);
+    if (r < 0) r = launch_gemm2(a, dtype, 4, true, 2, st);   // few workgroups: any tile that divides Cout
     SD_CHECK(r >= 0, "conv3x3: no 8-wave tile divides Cout=%d", Cout);
     return r;
   }
@@ -502,8 +503,8 @@ extern "C" int sdamd_conv3x3(const void* x, const void* w, void* y, const float*
   if (int e = check_common(a, dtype, "conv3x3")) return e;
   const int bke = dtype == SDAMD_BF16 ? 64 : 32;
   SD_CHECK(Cin % bke == 0, "conv3x3: Cin=%d must be a multiple of %d (use the small-channel kernels)", Cin, bke);
-  if (dtype == SDAMD_BF16 && g_gemm_impl != 1) {
-    const int r = launch_gemm2_bf16(a, 1, true, g_gemm_impl, st);
+  if (g_gemm_impl != 1) {
+    const int r = launch_gemm2(a, dtype, 1, true, g_gemm_impl, st);
     if (r >= 0) return r;
   }
   if (dtype == SDAMD_BF16) return pick_tile<bf16_t, true>(a, 1, st);

@@ -140,7 +140,7 @@ def conv1x1(x, conv, residual=None, out_dtype=None, compute_dtype=None):
 
 
 def conv3x3(x, conv, residual=None, stride=1, pad_mode=0, upsample=False, bias=None, out_dtype=None):
-    if upsample and residual is None and stride == 1 and pad_mode == 0 and x.dtype == torch.bfloat16 and \
+    if upsample and residual is None and stride == 1 and pad_mode == 0 and \
             ops.gemm_supports_act(ops.ACT_GEGLU, torch.bfloat16, 256) and \
             (conv.out_channels % 160 == 0 or conv.out_channels % 256 == 0):
         # nearest-2x + conv3x3 as four 2x2 phase convs (4/9 of the MACs), see conv3x3_up_phase_w
