@@ -277,3 +277,32 @@ def test_generate_errors_match_reference(models):
         pipeline.generate("synthetic:0", "", sampler="ddim", steps=2, **kw)
     with pytest.raises(Exception, match="HIP device"):
         pipeline.generate("synthetic:0", "", models=models, device="cpu", tokenizer=synth.SyntheticTokenizer())
+
+
+# ------------------------------------------------------------------ converter + loader
+def test_loader_from_standard_checkpoint_end_to_end(models, tmp_path):
+    """The hashed weights written out in CompVis checkpoint layout (full SD v1.5 size, .safetensors),
+    read back through loader.preload_models_from_standard_weights: every parameter bit-equal, and the
+    loaded models reproduce the reference's golden outputs."""
+    from safetensors.torch import save_file
+    from sd_amd import loader, model_converter
+    std = model_converter.to_standard_weights({k: {n: t.cpu() for n, t in m.state_dict().items()} for k, m in models.items()})
+    path = str(tmp_path / "v1-5-synthetic.safetensors")
+    save_file({k: v.contiguous() for k, v in std.items()}, path)
+    del std
+    loaded = loader.preload_models_from_standard_weights(path, device=DEV)
+    assert set(loaded) == {"clip", "encoder", "decoder", "diffusion"}
+    for name, m in loaded.items():
+        want = models[name].state_dict()
+        got = m.state_dict()
+        assert set(got) == set(want), name
+        for k in want:
+            assert got[k].is_cuda and torch.equal(got[k], want[k]), (name, k)
+    g = golden("clip")
+    ctx = loaded["clip"](torch.from_numpy(g["tokens"]).to(DEV))
+    assert rel_l2(ctx.cpu(), g["out"]) < TOL[FP32]
+    gd = golden("diffusion")
+    out = loaded["diffusion"](hin("diff.lat.16", (2, 4, 16, 16), 2.0).to(DEV), ctx, pipeline.get_time_embedding(500).to(DEV))
+    assert rel_l2(out.cpu(), gd["out16"]) < TOL[FP32]
+    dec = loaded["decoder"](hin("dec.lat.8", (2, 4, 8, 8), 0.5).to(DEV))
+    assert rel_l2(dec.cpu(), golden("vae_decoder")["dec8"]) < TOL[FP32]

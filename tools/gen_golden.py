@@ -6,7 +6,7 @@ imports the reference's modules unmodified, fills them with the hash weights of
 ``stable-diffusion_amd/synth.py`` (same state_dict keys), feeds hash/seeded inputs and
 stores the outputs.  Fixtures are data only -- no reference source is copied.
 
-    python tools/gen_golden.py [small] [models] [pipe3] [img2img] [pipe50]
+    python tools/gen_golden.py [keys] [small] [models] [pipe3] [img2img] [pipe50] [converter]
 """
 import contextlib
 import io
@@ -214,6 +214,44 @@ def gen_keys():
     save("state_dict_keys", **out)
 
 
+def gen_converter():
+    """Run the reference's model_converter on a synthetic CompVis-layout checkpoint and record what
+    it produced.  The checkpoint's key list is read out of the reference's text (the quoted
+    ``original_model[...]`` subscripts, i.e. the file format it expects -- data, not code); tensors are
+    tiny (shape [2, 3], rank-1 for biases) except the eight VAE attention conv weights whose reshape
+    targets are literal (model_converter.py:1040-1045).  Values are hash_uniform("ckpt:" + key)."""
+    import json
+    import re
+    import zlib
+    import tempfile
+    from safetensors.torch import save_file
+    import model_converter as ref_conv
+    text = open("/root/reference/src/model_converter.py").read()
+    keys = list(dict.fromkeys(re.findall(r"original_model\['([^']+)'\]", text)))
+    shapes = {}
+    for k in keys:
+        if re.search(r"mid\.attn_1\.(q|k|v|proj_out)\.weight$", k):
+            shapes[k] = (512, 512, 1, 1)
+        elif re.search(r"mid\.attn_1\.(q|k|v|proj_out)\.bias$", k):
+            shapes[k] = (512,)
+        else:
+            shapes[k] = (3,) if k.endswith(".bias") else (2, 3)
+    ckpt = {k: torch.from_numpy(synth.hash_uniform("ckpt:" + k, int(np.prod(s))).reshape(s)) for k, s in shapes.items()}
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "synthetic.safetensors")
+        save_file(ckpt, path)
+        conv = quiet(ref_conv.load_from_standard_weights, path, "cpu")
+    out = {"source": {k: list(s) for k, s in shapes.items()}, "converted": {}}
+    for model, sd in conv.items():
+        out["converted"][model] = {k: {"shape": list(v.shape), "crc32": zlib.crc32(v.contiguous().numpy().tobytes())}
+                                   for k, v in sd.items()}
+    path = os.path.join(GOLD, "converter_map.json")
+    with open(path, "w") as f:
+        json.dump(out, f, indent=0, sort_keys=True)
+    n = sum(len(v) for v in out["converted"].values())
+    print(f"  wrote converter_map.json  {len(keys)} source keys -> {n} converted keys  {os.path.getsize(path) / 1024:.0f} KB")
+
+
 def main():
     what = set(sys.argv[1:]) or {"small", "models", "pipe3"}
     os.makedirs(GOLD, exist_ok=True)
@@ -231,6 +269,8 @@ def main():
         pil = Image.fromarray(rng.integers(0, 256, (512, 512, 3), dtype=np.uint8))
         # literal reference semantics: start_step = 1000 - int(1000*0.998) = 2 -> 3 of 5 steps
         gen_pipeline(5, "pipeline_img2img_5step_s0998", input_image=pil, strength=0.998)
+    if "converter" in what:
+        gen_converter()
     if "pipe50" in what:
         gen_pipeline(50, "pipeline_txt2img_50step", every=1)
 
