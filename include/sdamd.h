@@ -38,9 +38,13 @@ int sdamd_device_count(void); /* >=0, or -hipError when no driver/GPU */
 /* ---- sampler: pipeline.py:147-153 (CFG combine) + sampler/ddpm.py:55-87 (step), one launch.
  * latents [B][n] f32 in/out; eps [2B][n] f32 = UNet output, [pos_0..pos_B-1, neg_0..neg_B-1]
  * (do_cfg=0: eps [B][n]); noise [steps][B][n] pre-drawn host noise (may be null when no row
- * has has_noise); coef [steps][8] = {sqrt(abar_t), sqrt(1-abar_t), c0, cx, sigma, has_noise,0,0}
- * computed on the host with the reference's own torch ops; the schedule index is *step_ptr
- * (device int, for graph replay) or `step` when step_ptr is null. Bit-exact vs torch CPU. */
+ * has has_noise); coef [steps][8] = {sqrt(abar_t), sqrt(1-abar_t), c0, cx, sigma, has_noise,
+ * cx_on_eps, 0} computed on the host in the reference's op order:
+ *   x0 = (x - sqrt(1-abar_t)*e) / sqrt(abar_t);  x' = x0*c0 + cx*(cx_on_eps ? e : x) [+ sigma*noise]
+ * cx_on_eps = 0 is the DDPM step (ddpm.py:59-85), 1 the deterministic DDIM step
+ * (sampler/ddim.py:50-72: c0 = sqrt(abar_prev), cx = sqrt(1-abar_prev), no noise).
+ * The schedule index is *step_ptr (device int, for graph replay) or `step` when step_ptr is
+ * null. Bit-exact vs torch CPU. */
 int sdamd_cfg_ddpm_step(float* latents, const float* eps, const float* noise, const float* coef,
                         const int* step_ptr, int step, float cfg_scale, int do_cfg, int B, int n,
                         void* stream);

@@ -288,6 +288,48 @@ class DDPMSampler:
         return float(np.sqrt(a)) * x + float(np.sqrt(np.float32(1) - a)) * noise
 
 
+class DDIMSampler:
+    """sampler/ddim.py:8-93 (eta = 0), same attribute names.  The reference's pipeline does not import
+    it (pipeline.py:4-5); the goldens were made with the class injected into the pipeline module."""
+
+    def __init__(self, generator, training_steps=1000):
+        scale = 1000 / training_steps                                               # :15-20
+        self.betas = torch.linspace(scale * 0.0001, scale * 0.02, training_steps, dtype=torch.float32)
+        self.alphas = 1.0 - self.betas
+        self.alpha_cumprod = torch.cumprod(self.alphas, 0)
+        self.one = torch.tensor(1.0)
+        self.generator = generator
+        self.training_steps = training_steps
+        self.set_steps(50)                                                          # :29-30
+
+    def set_steps(self, steps):                                                     # :32-36
+        self.steps = steps
+        ratio = self.training_steps // steps
+        self.timesteps = torch.from_numpy(
+            (np.arange(0, steps) * ratio).round()[::-1].copy().astype(np.int64))
+
+    def set_strength(self, strength=0.7):                                           # :42-45 (literal)
+        self.start_step = self.training_steps - int(self.training_steps * strength)
+        self.timesteps = self.timesteps[self.timesteps >= self.start_step]
+
+    def _prev(self, t):                                                             # :38-40
+        return max(int(t) - self.training_steps // self.steps, 0)
+
+    def step(self, t, latents, model_output, noise=None):                           # :50-72
+        f = np.float32
+        a_t = f(self.alpha_cumprod[int(t)].item())
+        a_p = f(self.alpha_cumprod[self._prev(t)].item())
+        sa, sb, ca, cb = (torch.tensor(v, dtype=torch.float32) for v in
+                          (np.sqrt(a_t), np.sqrt(f(1) - a_t), np.sqrt(a_p), np.sqrt(f(1) - a_p)))
+        x0 = (latents - model_output * sb) / sa
+        return ca * x0 + cb * model_output
+
+    add_noise = DDPMSampler.add_noise                                               # :74-93, same math
+
+
+SAMPLERS = {"ddpm": DDPMSampler, "ddim": DDIMSampler}
+
+
 def get_time_embedding(t):
     """pipeline.py:186-190."""
     freqs = torch.pow(10000, -torch.arange(0, 160, dtype=torch.float32) / 160)
@@ -302,7 +344,7 @@ def rescale(x, old, new, clamp=False):
 
 
 def generate(models, pos_ids, neg_ids, seed, steps=50, cfg_scale=7.5, input_image=None,
-             strength_start=None, preview_every_step=False, latent_hw=(64, 64), trace=None):
+             strength_start=None, preview_every_step=False, latent_hw=(64, 64), trace=None, sampler="ddpm"):
     """txt2img / img2img restatement of pipeline.generate (pipeline.py:15-171), batch 1.
 
     models: dict of state_dicts {"clip","diffusion","decoder","encoder"}.  Token ids go in
@@ -315,7 +357,7 @@ def generate(models, pos_ids, neg_ids, seed, steps=50, cfg_scale=7.5, input_imag
     g = torch.Generator().manual_seed(seed)
     ctx = torch.cat([clip_forward(models["clip"], torch.tensor([pos_ids])),
                      clip_forward(models["clip"], torch.tensor([neg_ids]))])        # :64 [pos; neg]
-    sampler = DDPMSampler(g)
+    sampler = SAMPLERS[sampler](g)
     sampler.set_steps(steps)
     shape = (1, 4, latent_hw[0], latent_hw[1])
     if input_image is not None:                                                     # :95-111

@@ -5,11 +5,13 @@
 #include "common.h"
 
 // ---------------------------------------------------------------------------------------------
-// CFG combine + DDPM ancestral step, one launch (pipeline.py:147-153 + ddpm.py:55-87).
+// CFG combine + sampler step, one launch (pipeline.py:147-153 + ddpm.py:55-87 / ddim.py:50-72).
 //   eps    [2B][n]  UNet output, images laid out [pos_0..pos_B-1, neg_0..neg_B-1]
 //   lat    [B][n]   in/out
 //   noise  [steps][B][n] pre-drawn on the host with the reference's generator call order
-//   coef   [steps][8] = {sqrt(abar_t), sqrt(1-abar_t), c0, cx, sigma, has_noise, 0, 0}
+//   coef   [steps][8] = {sqrt(abar_t), sqrt(1-abar_t), c0, cx, sigma, has_noise, cx_on_eps, 0}
+//     x0 = (x - sqrt(1-abar_t) * e) / sqrt(abar_t);   x' = x0 * c0 + cx * (cx_on_eps ? e : x) [+ sigma * noise]
+//     DDPM: cx weighs the current sample; DDIM (eta = 0): cx = sqrt(1-abar_prev) weighs the predicted noise.
 //   step_ptr: device int holding the schedule index (advanced by sdamd_counter_add between
 //   graph replays), or null to use `step`.
 // ---------------------------------------------------------------------------------------------
@@ -20,7 +22,7 @@ __global__ __launch_bounds__(256) void cfg_ddpm_step_kernel(float* __restrict__ 
   const int s = step_ptr ? *step_ptr : step;
   const float* c = coef + (size_t)s * 8;
   const float sa = c[0], sb = c[1], c0 = c[2], cx = c[3], sigma = c[4];
-  const bool has_noise = c[5] != 0.0f;
+  const bool has_noise = c[5] != 0.0f, cx_on_eps = c[6] != 0.0f;
   const size_t total = (size_t)B * n;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
     float e;
@@ -32,7 +34,7 @@ __global__ __launch_bounds__(256) void cfg_ddpm_step_kernel(float* __restrict__ 
     }
     float x = lat[i];
     float x0 = (x - sb * e) / sa;
-    float prev = x0 * c0 + cx * x;
+    float prev = x0 * c0 + cx * (cx_on_eps ? e : x);
     if (has_noise) prev = prev + sigma * noise[(size_t)s * total + i];
     lat[i] = prev;
   }

@@ -15,7 +15,8 @@ import numpy as np
 import torch
 
 from . import engine, ops
-from .sampler.ddpm import DDPMSampler
+from .sampler.ddim import DDIMSampler  # noqa: F401  (resolved by name, see _resolve_sampler)
+from .sampler.ddpm import DDPMSampler  # noqa: F401
 
 WIDTH = 512
 HEIGHT = 512
@@ -157,7 +158,8 @@ def prepare_latents(seeds, sampler_cls, steps, shape, device, encoder=None, imag
                     strength_semantics="reference"):
     """Per image: its own CPU generator and the reference's RNG call order:
     txt2img: randn(latents) then one randn per step with t>0; img2img: randn(encoder noise),
-    randn(add_noise), then the per-step draws.  Returns (timesteps, coef, noise [S,B,...], latents)."""
+    randn(add_noise), then the per-step draws (none for a deterministic sampler: noise is None).
+    Returns (timesteps, coef, noise [S,B,...], latents)."""
     samplers = []
     for s in seeds:
         g = torch.Generator(device="cpu")
@@ -174,7 +176,7 @@ def prepare_latents(seeds, sampler_cls, steps, shape, device, encoder=None, imag
         if len(samplers[0].timesteps) == 0:
             raise IndexError(
                 f"strength={strength} leaves no timesteps with the reference's set_strength semantics "
-                f"(sampler/ddpm.py:50-53 slices {steps} steps at {samplers[0].start_step}); "
+                f"(sampler/ddpm.py:50-53, start_step {samplers[0].start_step} of {steps} steps); "
                 "pass strength_semantics='intended'")
         t0 = samplers[0].timesteps[0]
         latents = torch.cat([sm.add_noise(latents[i:i + 1], t0) for i, sm in enumerate(samplers)])
@@ -182,11 +184,13 @@ def prepare_latents(seeds, sampler_cls, steps, shape, device, encoder=None, imag
         latents = torch.stack([sm.draw_noise(shape[1:]) for sm in samplers]).to(device)
     timesteps = samplers[0].timesteps
     coef = samplers[0].coefficient_table(timesteps)
-    noise = torch.zeros((len(timesteps), len(seeds)) + tuple(shape[1:]), dtype=torch.float32)
-    for si, t in enumerate(timesteps):
-        if int(t) > 0:
-            for bi, sm in enumerate(samplers):
-                noise[si, bi] = sm.draw_noise(shape[1:])
+    noise = None
+    if sampler_cls.stochastic:
+        noise = torch.zeros((len(timesteps), len(seeds)) + tuple(shape[1:]), dtype=torch.float32)
+        for si, t in enumerate(timesteps):
+            if int(t) > 0:
+                for bi, sm in enumerate(samplers):
+                    noise[si, bi] = sm.draw_noise(shape[1:])
     return timesteps, coef, noise, latents
 
 

@@ -1,3 +1,4 @@
+from .ddim import DDIMSampler
 from .ddpm import DDPMSampler
 
-__all__ = ["DDPMSampler"]
+__all__ = ["DDPMSampler", "DDIMSampler"]

@@ -13,6 +13,8 @@ from .. import ops
 
 
 class DDPMSampler:
+    stochastic = True       # one N(0,1) draw per step with t > 0 (ddpm.py:79-83)
+
     def __init__(self, generator: torch.Generator, training_steps=1000, beta_start: float = 0.00085,
                  beta_end: float = 0.0120):
         self.betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, training_steps, dtype=torch.float32) ** 2

@@ -152,11 +152,11 @@ def test_state_dict_keys_are_the_reference_abi(models):
 
 
 # ------------------------------------------------------------------ pipeline.generate
-def _gen(models, dtype, **kw):
+def _gen(models, dtype, sampler="ddpm", **kw):
     for m in models.values():
         with_dtype(m, dtype)
     trace = []
-    img, final = pipeline.generate("synthetic:0", "", models=models, seed=42, device="cuda", sampler="ddpm", cfg_scale=7.5,
+    img, final = pipeline.generate("synthetic:0", "", models=models, seed=42, device="cuda", sampler=sampler, cfg_scale=7.5,
                                    tokenizer=synth.SyntheticTokenizer(), compute_dtype=dtype, trace=trace,
                                    return_latents=True, **kw)
     return img, torch.stack([t.cpu() for t in trace]), final
@@ -189,6 +189,17 @@ def test_generate_txt2img_3step_vs_reference(models, dtype):
     img, lat, final = _gen(models, dtype, steps=3)
     errs = [rel_l2(lat[i], g["latents"][i]) for i in range(3)]
     print(f"\n[{dtype}] 3-step free-running rel-L2: " + " ".join(f"{e:.1e}" for e in errs))
+    assert max(errs) < TOL[dtype], errs
+    _check_final_image(models, img, final, g, dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_generate_txt2img_ddim_3step_vs_reference(models, dtype):
+    """sampler="ddim" (SURVEY §8f-3): the reference's DDIMSampler driven by its own pipeline loop."""
+    g = golden("pipeline_txt2img_ddim_3step")
+    img, lat, final = _gen(models, dtype, sampler="ddim", steps=3)
+    errs = [rel_l2(lat[i], g["latents"][i]) for i in range(3)]
+    print(f"\n[{dtype}] DDIM 3-step free-running rel-L2: " + " ".join(f"{e:.1e}" for e in errs))
     assert max(errs) < TOL[dtype], errs
     _check_final_image(models, img, final, g, dtype)
 
@@ -273,8 +284,8 @@ def test_generate_errors_match_reference(models):
     kw = dict(models=models, device="cuda", tokenizer=synth.SyntheticTokenizer())
     with pytest.raises(ValueError, match="Strength must be between 0 and 1"):
         pipeline.generate("synthetic:0", "", strength=0.0, **kw)
-    with pytest.raises(ValueError, match="Sampler 'ddim' not found"):
-        pipeline.generate("synthetic:0", "", sampler="ddim", steps=2, **kw)
+    with pytest.raises(ValueError, match="Sampler 'euler' not found"):     # pipeline.py:84 (euler.py is never imported)
+        pipeline.generate("synthetic:0", "", sampler="euler", steps=2, **kw)
     with pytest.raises(Exception, match="HIP device"):
         pipeline.generate("synthetic:0", "", models=models, device="cpu", tokenizer=synth.SyntheticTokenizer())
 

@@ -98,6 +98,34 @@ def test_sampler_step_and_add_noise_match_golden():
     assert rel_l2(sm.add_noise(x, torch.tensor(780)).cpu(), g["add_noise_780"]) < 1e-6
 
 
+def test_ddim_step_matches_golden():
+    """sampler/ddim.py:50-72 through the fused step kernel (cx_on_eps row): bit-exact vs the reference class."""
+    from conftest import golden
+    from sd_amd.sampler.ddim import DDIMSampler
+    g = golden("ddim_step")
+    for steps, ts in ((50, (980, 500, 20, 0)), (20, (950, 0))):
+        for t in ts:
+            sm = DDIMSampler(torch.Generator().manual_seed(1))
+            sm.set_steps(steps)
+            lat, eps = hin(f"ddim.lat.{t}", (1, 4, 16, 16), 2.0).to(DEV), hin(f"ddim.eps.{t}", (1, 4, 16, 16), 1.5).to(DEV)
+            assert np.array_equal(sm.step(t, lat, eps).cpu().numpy(), g[f"step{steps}_{t}"]), (steps, t)
+    # CFG combine + DDIM step in one launch, schedule index from the device counter, no noise buffer
+    sm = DDIMSampler(torch.Generator().manual_seed(1))
+    coef = sm.coefficient_table()
+    B = 2
+    lat, eps = rnd("ddim.cfg.lat", (B, 4, 16, 16), 2.0), rnd("ddim.cfg.eps", (2 * B, 4, 16, 16), 1.5)
+    for si in (0, 31, 49):
+        c = coef[si]
+        e = 7.5 * (eps[:B] - eps[B:]) + eps[B:]
+        want = ((lat - c[1] * e) / c[0]) * c[2] + c[3] * e
+        ctr = torch.tensor([si], dtype=torch.int32, device=DEV)
+        got = ops.cfg_ddpm_step(lat.to(DEV).clone(), eps.to(DEV), None, coef.to(DEV), 0, 7.5, step_ptr=ctr).cpu()
+        assert torch.equal(got, want), si
+    sm = DDIMSampler(torch.Generator().manual_seed(77))
+    x = hin("ddim.an", (1, 4, 16, 16)).to(DEV)
+    assert rel_l2(sm.add_noise(x, torch.tensor(780)).cpu(), g["add_noise_780"]) < 1e-6
+
+
 def test_gather_row_and_silu():
     table = rnd("gather", (5, 96))
     dst = torch.empty(96, device=DEV)

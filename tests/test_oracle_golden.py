@@ -52,6 +52,34 @@ def test_ddpm_step_bit_exact():
     assert rel_l2(sm.add_noise(x, torch.tensor(780)), g["add_noise_780"]) < 1e-6
 
 
+def test_ddim_tables_and_step_bit_exact():
+    """Oracle DDIMSampler and the product's host-side schedule vs the reference class (sampler/ddim.py)."""
+    from sd_amd.sampler.ddim import DDIMSampler as ProductDDIM
+    g = golden("ddim_step")
+    for cls in (O.DDIMSampler, ProductDDIM):
+        s = cls(torch.Generator().manual_seed(0))
+        assert np.array_equal(s.alpha_cumprod.numpy(), g["alpha_cumprod"])
+        assert np.array_equal(s.betas.numpy(), g["betas"])
+        assert np.array_equal(s.timesteps.numpy(), g["timesteps_default"])      # 50 steps set by the constructor
+        s.set_steps(20)
+        assert np.array_equal(s.timesteps.numpy(), g["timesteps20"])
+        s.set_steps(50); s.set_strength(0.8)
+        assert np.array_equal(s.timesteps.numpy(), g["timesteps50_strength08"])  # keeps t >= 200 (literal)
+    for steps, ts in ((50, (980, 500, 20, 0)), (20, (950, 0))):
+        for t in ts:
+            sm = O.DDIMSampler(torch.Generator().manual_seed(1)); sm.set_steps(steps)
+            lat, eps = hin(f"ddim.lat.{t}", (1, 4, 16, 16), 2.0), hin(f"ddim.eps.{t}", (1, 4, 16, 16), 1.5)
+            assert np.array_equal(sm.step(t, lat, eps).numpy(), g[f"step{steps}_{t}"]), (steps, t)
+            # the product's coefficient row holds the same four scalars the oracle uses
+            pm = ProductDDIM(torch.Generator().manual_seed(1)); pm.set_steps(steps)
+            c = pm.step_coefficients(t).numpy()
+            want = ((lat - eps * c[1]) / c[0]) * c[2] + c[3] * eps
+            assert np.array_equal(want.numpy(), g[f"step{steps}_{t}"]) and tuple(c[4:]) == (0, 0, 1, 0)
+    sm = O.DDIMSampler(torch.Generator().manual_seed(77)); sm.set_steps(50)
+    x = hin("ddim.an", (1, 4, 16, 16))
+    assert np.array_equal(sm.add_noise(x, torch.tensor(780), noise=torch.from_numpy(g["add_noise_780_noise"])).numpy(), g["add_noise_780"])
+
+
 def _attn_shapes(dim, bias_in, cross=False):
     if cross:
         s = {"q_proj.weight": (dim, dim), "k_proj.weight": (dim, 768), "v_proj.weight": (dim, 768)}
@@ -152,6 +180,19 @@ def test_pipeline_txt2img_3step(model_sds, diffusion_sd):
     models = dict(model_sds, diffusion=diffusion_sd)
     trace = []
     img = O.generate(models, synth.synthetic_token_ids(0), synth.EMPTY_PROMPT_IDS, seed=42, steps=3, trace=trace)
+    for i in range(3):
+        assert rel_l2(trace[i], g["latents"][i]) < TOL_MODEL, i
+    diff = np.abs(img.astype(np.int32) - g["image"].astype(np.int32))
+    assert diff.max() <= 1 and (diff > 0).mean() < 0.01
+
+
+@pytest.mark.slow
+def test_pipeline_txt2img_ddim_3step(model_sds, diffusion_sd):
+    """Oracle generate(sampler="ddim") vs the reference's pipeline.generate with its DDIMSampler injected."""
+    g = golden("pipeline_txt2img_ddim_3step")
+    models = dict(model_sds, diffusion=diffusion_sd)
+    trace = []
+    img = O.generate(models, synth.synthetic_token_ids(0), synth.EMPTY_PROMPT_IDS, seed=42, steps=3, trace=trace, sampler="ddim")
     for i in range(3):
         assert rel_l2(trace[i], g["latents"][i]) < TOL_MODEL, i
     diff = np.abs(img.astype(np.int32) - g["image"].astype(np.int32))

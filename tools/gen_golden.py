@@ -6,7 +6,7 @@ imports the reference's modules unmodified, fills them with the hash weights of
 ``stable-diffusion_amd/synth.py`` (same state_dict keys), feeds hash/seeded inputs and
 stores the outputs.  Fixtures are data only -- no reference source is copied.
 
-    python tools/gen_golden.py [keys] [small] [models] [pipe3] [img2img] [pipe50] [converter]
+    python tools/gen_golden.py [keys] [small] [models] [pipe3] [img2img] [pipe50] [converter] [ddim]
 """
 import contextlib
 import io
@@ -214,6 +214,50 @@ def gen_keys():
     save("state_dict_keys", **out)
 
 
+def gen_ddim():
+    """The reference's DDIMSampler class (sampler/ddim.py) and a 3-step generate() through it.  The
+    reference pipeline forgot the import (pipeline.py:4-5): the class is put into the pipeline module's
+    namespace from here -- no reference file is modified."""
+    from sampler.ddim import DDIMSampler as RefDDIM
+    s = RefDDIM(torch.Generator().manual_seed(0))
+    t_default = s.timesteps.clone()
+    s20 = RefDDIM(torch.Generator().manual_seed(0)); s20.set_steps(20)
+    s08 = RefDDIM(torch.Generator().manual_seed(0)); s08.set_steps(50); s08.set_strength(0.8)
+    out = dict(alpha_cumprod=s.alpha_cumprod, betas=s.betas, timesteps_default=t_default, timesteps20=s20.timesteps,
+               timesteps50_strength08=s08.timesteps)
+    for steps, ts in ((50, (980, 500, 20, 0)), (20, (950, 0))):
+        for t in ts:
+            sm = RefDDIM(torch.Generator().manual_seed(1)); sm.set_steps(steps)
+            lat = hin(f"ddim.lat.{t}", (1, 4, 16, 16), 2.0)
+            eps = hin(f"ddim.eps.{t}", (1, 4, 16, 16), 1.5)
+            out[f"step{steps}_{t}"] = sm.step(t, lat, eps)
+    sm = RefDDIM(torch.Generator().manual_seed(77)); sm.set_steps(50)
+    out["add_noise_780"] = sm.add_noise(hin("ddim.an", (1, 4, 16, 16)), torch.tensor(780))
+    out["add_noise_780_noise"] = torch.randn((1, 4, 16, 16), generator=torch.Generator().manual_seed(77))
+    save("ddim_step", **out)
+    # pipeline: trace DDIM's step like _Trace does for DDPM
+    ref_pipeline.DDIMSampler = RefDDIM
+    m = ref_models()
+    rec, orig = [], RefDDIM.step
+
+    def step(inner_self, t, lat, eps):
+        o = orig(inner_self, t, lat, eps)
+        rec.append(o.clone())
+        return o
+
+    RefDDIM.step = step
+    try:
+        t0 = time.time()
+        img = quiet(ref_pipeline.generate, "synthetic:0", "", models=m, seed=42, device="cpu", sampler="ddim", steps=3,
+                    cfg_scale=7.5, tokenizer=synth.SyntheticTokenizer())
+        print(f"  reference generate(ddim, 3 steps) {time.time() - t0:.0f}s", flush=True)
+    finally:
+        RefDDIM.step = orig
+        del ref_pipeline.DDIMSampler
+    save("pipeline_txt2img_ddim_3step", image=img, latents=torch.stack(rec), latent_steps=np.arange(len(rec), dtype=np.int64),
+         n_steps=np.int64(len(rec)))
+
+
 def gen_converter():
     """Run the reference's model_converter on a synthetic CompVis-layout checkpoint and record what
     it produced.  The checkpoint's key list is read out of the reference's text (the quoted
@@ -269,6 +313,8 @@ def main():
         pil = Image.fromarray(rng.integers(0, 256, (512, 512, 3), dtype=np.uint8))
         # literal reference semantics: start_step = 1000 - int(1000*0.998) = 2 -> 3 of 5 steps
         gen_pipeline(5, "pipeline_img2img_5step_s0998", input_image=pil, strength=0.998)
+    if "ddim" in what:
+        gen_ddim()
     if "converter" in what:
         gen_converter()
     if "pipe50" in what:
