@@ -21,7 +21,7 @@ struct AttnArgs {
   long long q_bs, k_bs, v_bs, o_bs;  // batch strides, elements
   int q_rs, k_rs, v_rs, o_rs;        // token strides, elements; head h starts at column h*D
   float scale_log2e;  // log2(e) / sqrt(D)
-  int debug;          // timing ablations only (experiments/attn_bench.py): 1 no softmax, 2 no PV, 3 no QK, 4 no staging, 5 no barrier
+  int debug;          // timing ablations (only in builds with -DSDAMD_ATTN_ABLATE): 1 no softmax, 2 no PV, 3 no QK, 4 no staging, 5 no barrier
   int causal;
 };
 
@@ -51,6 +51,14 @@ typedef __attribute__((ext_vector_type(2))) float f32x2_t;
 constexpr float RESCALE_THR = 8.0f;
 
 // (forcing 4 waves/SIMD through __launch_bounds__ spills 8-27 registers and measured slower)
+// Runtime ablation switches split the K/V loop into a dozen basic blocks (no scheduling across them: every
+// fragment read was followed by its own wait): they only exist in -DSDAMD_ATTN_ABLATE builds.
+#ifdef SDAMD_ATTN_ABLATE
+#define ATTN_DBG(x) (p.debug == (x))
+#else
+#define ATTN_DBG(x) false
+#endif
+
 template <typename T, int D>
 __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs p) {
   typedef AttnCfg<T, D> Cfg;
@@ -167,7 +175,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs p) {
     const int kv0 = kt * BKV;
     const char* ks = smem + (kt & 1) * STAGE;
     const char* vs = ks + BKV * KS;
-    if (kt + 1 < ntiles && p.debug != 4 && p.debug != 5) issue(kv0 + BKV);
+    if (kt + 1 < ntiles && !ATTN_DBG(4) && !ATTN_DBG(5)) issue(kv0 + BKV);
 
     // Per 32-key sub-tile: S^T = K Q^T (rows = keys in the accumulator registers, cols = queries on
     // the lanes) -> online softmax (log2 domain) -> O^T += V^T P^T.  Program order is
@@ -217,7 +225,8 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs p) {
       const f32x2_t sc2 = {sc, sc}, nm2 = {-m_new, -m_new};
 #pragma unroll
       for (int e = 0; e < 16; e += 2) {
-        const f32x2_t a = (f32x2_t){s[sub][e], s[sub][e + 1]} * sc2 + nm2;   // v_pk_fma_f32
+        // v_pk_fma_f32 (measured: scalar v_fma_f32 + -fno-slp-vectorize is 2.5 % slower here)
+        const f32x2_t a = (f32x2_t){s[sub][e], s[sub][e + 1]} * sc2 + nm2;
         const float p0 = __builtin_amdgcn_exp2f(a[0]), p1 = __builtin_amdgcn_exp2f(a[1]);
         s[sub][e] = p0;
         s[sub][e + 1] = p1;
@@ -273,15 +282,15 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs p) {
       }
     };
 #pragma unroll
-    for (int sub = 0; sub < NSUB; ++sub) if (p.debug != 3) qk(sub);
+    for (int sub = 0; sub < NSUB; ++sub) if (!ATTN_DBG(3)) qk(sub);
 #pragma unroll
     for (int sub = 0; sub < NSUB; ++sub) {
-      if (p.debug != 1) softmax(sub);
-      if (p.debug != 2) pv(sub);
+      if (!ATTN_DBG(1)) softmax(sub);
+      if (!ATTN_DBG(2)) pv(sub);
     }
 
-    if (kt + 1 < ntiles && p.debug != 4 && p.debug != 5) commit((kt + 1) & 1);
-    if (p.debug != 5) __syncthreads();
+    if (kt + 1 < ntiles && !ATTN_DBG(4) && !ATTN_DBG(5)) commit((kt + 1) & 1);
+    if (!ATTN_DBG(5)) __syncthreads();
   }
 
   // epilogue: O[q][d] = O^T[d][q] / l ; lane holds d = 32i + 8*(e>>2) + 4h + (e&3)
