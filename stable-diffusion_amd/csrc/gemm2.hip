@@ -492,7 +492,12 @@ int gemm2_choose_tile(int M, int N, int K, int batch, int mode, size_t ws_bytes,
     if (s >= 1 && s <= max_splits() && s <= nk) *splits = s;
     return tiles[((g_gemm_debug - 32) >> 3) & 3];
   }
-  if (N % 320 == 0 && blocks(128, 320) >= 256) return 128320;
+  // bf16: the 4-wave 128x160 tile (two co-resident workgroups per CU overlap each other's prologue and
+  // epilogue) beats the 8-wave 128x320 one by 3-9 % once it fills two rounds (>= 512 workgroups), except on
+  // short-K GEMMs with many 128x320 tiles (measured at UNet batch 16, experiments/gemm_bench.py 0,8448)
+  const long long b160 = N % 160 == 0 ? blocks(128, 160) : 0, b320 = N % 320 == 0 ? blocks(128, 320) : 0;
+  if (bke == 64 && b160 >= 512 && (K >= 2560 || b320 < 512)) return 128160;
+  if (b320 >= 256) return 128320;
   if (bke == 32) {
     // f32 operands (exact 16x16x4 MFMA, ~4x the issue cycles per byte staged): the 8-wave layout only
     // wins over the register-staged 64-wide tiles once >= 256 workgroups exist (measured at UNet
