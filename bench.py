@@ -108,19 +108,27 @@ def roofline_leg(models, args, device):
                      "achieved": round(rate, 2), "unit": "TFLOP/s" if mfma else "GB/s",
                      "frac": round(rate / (PEAK[dt] if mfma else PEAK["hbm"]), 4)})
     rows.sort(key=lambda r: -r["total_ms"])
-    top = rows[0]
-    work = summ[top["kernel"]]["work"] / top["launches"]
-    roof = {"kernel": top["kernel"], "symbol": kernel_symbol(top["kernel"]), "bound": top["bound"],
-            "achieved": top["achieved"],
-            "peak": PEAK["bf16" if "_bf16" in top["kernel"] else "f32"] if top["bound"] == "mfma" else PEAK["hbm"],
-            "unit": top["unit"], "frac": top["frac"], "traffic": pmc_traffic(kernel_symbol(top["kernel"])),
-            "launches": top["launches"], "avg_launch_us": top["avg_us"],
-            "algorithmic_work_per_launch": round(work / (1e9 if top["bound"] == "mfma" else 1e6), 3),
-            "work_unit": "GFLOP" if top["bound"] == "mfma" else "MB",
-            "note": "dominant kernel instantiation of one bench step (most summed time): mean algorithmic FLOPs per launch / "
-                    "mean launch duration, HIP events on the launch stream in one extra eager pass; traffic = mean HBM bytes "
-                    "per launch from profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
-                    "command, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950), null if not collected"}
+    # the roofline object is per kernel SYMBOL (what a rocprofv3 trace shows): split-K variants and all
+    # problem shapes of one template instantiation are one entry
+    by_sym = {}
+    for kind, v in summ.items():
+        e = by_sym.setdefault(kernel_symbol(kind), {"ms": 0.0, "work": 0.0, "launches": 0, "kinds": []})
+        e["ms"] += v["ms"]; e["work"] += v["work"]; e["launches"] += v["launches"]; e["kinds"].append(kind)
+    sym, top = max(by_sym.items(), key=lambda kv: kv[1]["ms"])
+    mfma = top["kinds"][0].split("_")[0] in ("conv3x3", "gemm", "attention")
+    dt = "bf16" if "_bf16" in top["kinds"][0] else "f32"
+    peak = PEAK[dt] if mfma else PEAK["hbm"]
+    rate = top["work"] / (top["ms"] * 1e-3) / (1e12 if mfma else 1e9)
+    roof = {"kernel": sym, "labels": sorted(top["kinds"]), "bound": "mfma" if mfma else "hbm",
+            "achieved": round(rate, 2), "peak": peak, "unit": "TFLOP/s" if mfma else "GB/s", "frac": round(rate / peak, 4),
+            "traffic": pmc_traffic(sym), "launches": top["launches"],
+            "avg_launch_us": round(1e3 * top["ms"] / top["launches"], 2),
+            "algorithmic_work_per_launch": round(top["work"] / top["launches"] / (1e9 if mfma else 1e6), 3),
+            "work_unit": "GFLOP" if mfma else "MB",
+            "note": "dominant kernel symbol of one bench step (most summed time over all its launches): mean algorithmic FLOPs per "
+                    "launch / mean launch duration, HIP events on the launch stream in one extra eager pass; traffic = mean HBM bytes "
+                    "per launch from profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over eager UNet "
+                    "steps, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950), null if not collected"}
     return roof, rows
 
 
@@ -130,10 +138,10 @@ def kernel_symbol(kind):
     if parts[0] in ("gemm", "conv3x3") and len(parts) >= 3 and "x" in parts[2]:
         bm, bn = parts[2].split("x")
         conv = "true" if parts[0] == "conv3x3" else "false"
-        if parts[1] == "bf16" and (bm, bn) in (("128", "320"), ("128", "160"), ("256", "256"), ("256", "160")):
-            wg = {"128x320": "2, 4, 2", "128x160": "2, 2, 2", "256x256": "2, 4, 2", "256x160": "4, 2, 3"}[parts[2]]
-            return f"gemm2_kernel<{bm}, {bn}, {wg}, {conv}>"
         t = "unsigned short" if parts[1] == "bf16" else "float"
+        wg = {"128x320": "2, 4, 2", "128x160": "2, 2, 2", "256x256": "2, 4, 2"}.get(parts[2])
+        if wg is not None:      # 8-wave / 4-wave LDS-DMA family (gemm2.hip)
+            return f"gemm2_kernel<{t}, {bm}, {bn}, {wg}, {conv}>"
         return f"gemm_kernel<{t}, {bm}, {bn}, {conv}>"
     if parts[0] == "attention":
         t = "unsigned short" if parts[1] == "bf16" else "float"

@@ -485,9 +485,8 @@ int gemm2_choose_tile(int M, int N, int K, int batch, int mode, size_t ws_bytes,
     return tile;
   }
   extern int g_gemm_debug;
-  if (g_gemm_debug == 4 && N % 160 == 0 && blocks(256, 160) >= 256) return 256160;   // experiment: 3-stage ring
   if (g_gemm_debug >= 32) {   // experiment: forced tile / split (debug = 32 + 8*tile + splits)
-    static const int tiles[4] = {128160, 128320, 256256, 256160};
+    static const int tiles[4] = {128160, 128320, 256256, 128128};
     const int s = (g_gemm_debug - 32) & 7;
     if (s >= 1 && s <= max_splits() && s <= nk) *splits = s;
     return tiles[((g_gemm_debug - 32) >> 3) & 3];
@@ -531,13 +530,14 @@ static int launch_gemm2_t(GemmArgs& a, int batch, bool conv, int mode, hipStream
   if (sizeof(T) == 2 && !a.out_f32 && ((a.ldc % 8) != 0 || (a.sC % 8) != 0)) return -1;   // 16-byte row-segment stores
   if (sizeof(T) == 4 && ((a.ldc % 4) != 0 || (a.sC % 4) != 0)) return -1;
   int tile = gemm2_choose_tile(a.M, a.N, a.K, batch, mode, a.ws ? a.ws_bytes : 0, &a.splits, 128 / (int)sizeof(T));
-  if (a.act == ACT_GEGLU) {   // needs an even number of 16-column tiles per wave: the 256x256 tile
+  if (a.act == ACT_GEGLU) {   // needs an even number of 16-column tiles per wave: 256x256 or 128x128
     if (sizeof(T) == 4 || conv || a.out_f32 || a.R || a.N % 256 != 0) return -1;
-    tile = 256256;
+    extern int g_gemm_debug;
+    tile = g_gemm_debug == 6 ? 128128 : 256256;
     a.splits = 1;
   }
   switch (tile) {
-    case 256160: return conv ? launch2<T, 256, 160, 4, 2, 3, true>(a, batch, st) : launch2<T, 256, 160, 4, 2, 3, false>(a, batch, st);
+    case 128128: return conv ? -1 : launch2<T, 128, 128, 2, 2, 2, false>(a, batch, st);
     case 128160: return conv ? launch2<T, 128, 160, 2, 2, 2, true>(a, batch, st) : launch2<T, 128, 160, 2, 2, 2, false>(a, batch, st);
     case 128320: return conv ? launch2<T, 128, 320, 2, 4, 2, true>(a, batch, st) : launch2<T, 128, 320, 2, 4, 2, false>(a, batch, st);
     case 256256: return conv ? launch2<T, 256, 256, 2, 4, 2, true>(a, batch, st) : launch2<T, 256, 256, 2, 4, 2, false>(a, batch, st);
