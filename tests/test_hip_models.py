@@ -317,3 +317,78 @@ def test_loader_from_standard_checkpoint_end_to_end(models, tmp_path):
     assert rel_l2(out.cpu(), gd["out16"]) < TOL[FP32]
     dec = loaded["decoder"](hin("dec.lat.8", (2, 4, 8, 8), 0.5).to(DEV))
     assert rel_l2(dec.cpu(), golden("vae_decoder")["dec8"]) < TOL[FP32]
+
+
+# ------------------------------------------------------------------ BASELINE configs 4 and 5 at their own sizes
+_ORACLE_CACHE = {}
+
+
+def _cpu_sds(models):
+    if "sd" not in _ORACLE_CACHE:
+        _ORACLE_CACHE["sd"] = {k: {n: t.cpu() for n, t in m.state_dict().items()} for k, m in models.items()}
+    return _ORACLE_CACHE["sd"]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_diffusion_at_latent_96(models, dtype):
+    """Config 5's UNet problem (768^2 image -> latent 96x96, 9216-token self-attention), batch 2, against the
+    CPU oracle at full size."""
+    lat, t320 = hin("diff.lat.96", (2, 4, 96, 96), 2.0), pipeline.get_time_embedding(740)
+    ctx = torch.from_numpy(golden("clip")["out"])
+    if "d96" not in _ORACLE_CACHE:
+        _ORACLE_CACHE["d96"] = O.diffusion_forward(_cpu_sds(models)["diffusion"], lat, ctx, t320)
+    out = with_dtype(models["diffusion"], dtype)(lat.to(DEV), ctx.to(DEV), t320.to(DEV))
+    assert tuple(out.shape) == (2, 4, 96, 96)
+    assert rel_l2(out.cpu(), _ORACLE_CACHE["d96"]) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_generate_768(models, dtype, monkeypatch):
+    """Config 5 end to end at batch 1: the reference switches resolution through its module constants
+    (pipeline.py:9-13); one CFG step + VAE decode to 768x768 against the oracle."""
+    for name, v in (("WIDTH", 768), ("HEIGHT", 768), ("LATENTS_WIDTH", 96), ("LATENT_HEIGHT", 96)):
+        monkeypatch.setattr(pipeline, name, v)
+    if "g768" not in _ORACLE_CACHE:
+        tr = []
+        img = O.generate(_cpu_sds(models), synth.synthetic_token_ids(0), synth.EMPTY_PROMPT_IDS, seed=42, steps=1,
+                         latent_hw=(96, 96), trace=tr)
+        _ORACLE_CACHE["g768"] = (img, tr[-1])
+    want_img, want_lat = _ORACLE_CACHE["g768"]
+    img, lat, final = _gen(models, dtype, steps=1)
+    assert img.shape == (768, 768, 3) and img.dtype == np.uint8
+    assert rel_l2(lat[-1], want_lat) < TOL[dtype]
+    diff = np.abs(img.astype(np.int32) - want_img.astype(np.int32))
+    if dtype == FP32:
+        assert diff.max() <= 1 and (diff > 0).mean() < 0.01
+    else:
+        assert rel_l2(img.astype(np.float32), want_img.astype(np.float32)) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_generate_img2img_strength08_batch(models, dtype):
+    """Config 4's workload (img2img, strength 0.8) needs the intended strength semantics (the literal ones leave no
+    timesteps, see test_generate_img2img_vs_reference): batch of 2 images with per-image seeds, 5-step schedule ->
+    the last 4 steps, each image against an independent oracle run."""
+    from PIL import Image
+    rng = np.random.default_rng(11)
+    pils = [Image.fromarray(rng.integers(0, 256, (512, 512, 3), dtype=np.uint8)) for _ in range(2)]
+    for m in models.values():
+        with_dtype(m, dtype)
+    imgs, final = pipeline.generate(["synthetic:0", "synthetic:1"], "", input_image=pils, strength=0.8, models=models, seed=42,
+                                    device="cuda", sampler="ddpm", steps=5, cfg_scale=7.5, tokenizer=synth.SyntheticTokenizer(),
+                                    compute_dtype=dtype, strength_semantics="intended", return_latents=True)
+    assert imgs.shape == (2, 512, 512, 3)
+    for i in range(2):
+        key = f"i2i{i}"
+        if key not in _ORACLE_CACHE:
+            tr = []
+            img = O.generate(_cpu_sds(models), synth.synthetic_token_ids(i), synth.EMPTY_PROMPT_IDS, seed=42 + i, steps=5,
+                             input_image=pils[i], strength_start=1, trace=tr)
+            _ORACLE_CACHE[key] = (img, tr[-1])
+        want_img, want_lat = _ORACLE_CACHE[key]
+        assert rel_l2(final[i:i + 1].cpu(), want_lat) < TOL[dtype], i
+        diff = np.abs(imgs[i].astype(np.int32) - want_img.astype(np.int32))
+        if dtype == FP32:
+            assert diff.max() <= 1 and (diff > 0).mean() < 0.01, i
+        else:
+            assert rel_l2(imgs[i].astype(np.float32), want_img.astype(np.float32)) < TOL[dtype], i
