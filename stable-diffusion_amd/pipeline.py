@@ -9,7 +9,8 @@ Differences a caller can observe (all documented in DESIGN.md):
   * ``fp16_enabled=True`` selects the bf16 kernels (the reference's fp16 autocast has no MI355X
     counterpart here); ``idle_device`` is accepted and ignored (288 GB of HBM: nothing to offload);
   * extensions: ``prompt`` may be a list (batch of independent images, image i uses ``seed + i``),
-    ``strength_semantics`` selects the img2img schedule slice, ``return_latents`` for tests.
+    ``strength_semantics`` selects the img2img schedule slice, ``return_latents`` for tests,
+    ``preview(step_index, timestep, uint8 images [B,H,W,3])`` restores the per-step decode as a callback.
 """
 import numpy as np
 import torch
@@ -136,7 +137,9 @@ def _resolve_sampler(name):
 
 
 def _token_tensor(tokenizer, prompts, device):
-    ids = tokenizer.batch_encode_plus(list(prompts), padding="max_length", max_length=77).input_ids
+    # pipeline.py:51-53 calls batch_encode_plus; transformers >= 5 dropped that alias of __call__
+    encode = getattr(tokenizer, "batch_encode_plus", None) or tokenizer
+    ids = encode(list(prompts), padding="max_length", max_length=77).input_ids
     return torch.tensor(ids, dtype=torch.long, device=device)
 
 
@@ -215,6 +218,7 @@ def generate(
     use_graph=True,
     return_latents=False,
     trace=None,
+    preview=None,
 ):
     with torch.no_grad():
         if not (0 < strength <= 1):
@@ -249,7 +253,15 @@ def generate(
             images_u8, strength, strength_semantics)
 
         loop = DenoiseLoop(models["diffusion"], context, timesteps, coef, noise, latents, cfg_scale, do_cfg, use_graph)
-        final = loop.run(trace)
+        if preview is None:
+            final = loop.run(trace)
+        else:   # the reference's per-step preview (pipeline.py:156-164) as an opt-in callback
+            for i in range(loop.n_steps):
+                loop.step()
+                if trace is not None:
+                    trace.append(loop.latents.clone())
+                preview(i, int(timesteps[i]), decode_to_uint8(models["decoder"], loop.latents.clone()).cpu().numpy())
+            final = loop.latents
         images = decode_to_uint8(models["decoder"], final)
         out = images.cpu().numpy()
         if return_latents:

@@ -392,3 +392,18 @@ def test_generate_img2img_strength08_batch(models, dtype):
             assert diff.max() <= 1 and (diff > 0).mean() < 0.01, i
         else:
             assert rel_l2(imgs[i].astype(np.float32), want_img.astype(np.float32)) < TOL[dtype], i
+
+
+def test_generate_preview_callback(models):
+    """The reference decodes + shows every step (pipeline.py:156-164); here that is the opt-in ``preview`` callback.
+    It must not change the result, and its last frame is the returned image."""
+    for m in models.values():
+        with_dtype(m, FP32)
+    kw = dict(models=models, seed=42, device="cuda", sampler="ddpm", steps=3, cfg_scale=7.5, tokenizer=synth.SyntheticTokenizer())
+    frames = []
+    img = pipeline.generate("synthetic:0", "", preview=lambda i, t, im: frames.append((i, t, im)), **kw)
+    ref = pipeline.generate("synthetic:0", "", **kw)
+    assert np.array_equal(img, ref)
+    assert [f[0] for f in frames] == [0, 1, 2] and [f[1] for f in frames] == [666, 333, 0]
+    assert frames[-1][2].shape == (1, 512, 512, 3) and np.array_equal(frames[-1][2][0], img)
+    assert not np.array_equal(frames[0][2][0], img)
