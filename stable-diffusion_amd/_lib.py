@@ -6,7 +6,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libsdamd.so")
+# SDAMD_LIB: another build of the same ABI (A/B experiments); never a fallback -- it must exist too
+LIB_PATH = os.environ.get("SDAMD_LIB") or os.path.join(_HERE, "csrc", "libsdamd.so")
 
 _vp, _i, _f, _ll, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_longlong, ctypes.c_size_t
 

@@ -41,6 +41,19 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+// Timing ablations: p.debug 1 = no DMA, 2 = no MFMA (experiments only; sdamd_set_gemm_impl(debug << 8)).
+// For the dense GEMM instantiations they are compiled out unless -DSDAMD_GEMM_ABLATE: as runtime branches they
+// split the K-loop body and cost the 8-wave 128x320 tile 6-12 %.  The CONV and 4-wave instantiations keep the
+// (always false) runtime test on purpose: with it hipcc unswitches the K loop and keeps each tile's gather-address
+// arithmetic next to its DMA issue; without it the address arithmetic of two tiles is scheduled between the
+// MFMAs of one and the 4-wave conv tile drops from 800-930 to 560-620 TFLOP/s (same box,
+// experiments/ab_conv.py).
+#ifdef SDAMD_GEMM_ABLATE
+#define GEMM2_DBG(x) (p.debug == (x))
+#else
+#define GEMM2_DBG(x) ((CONV || WGM * WGN == 4) && p.debug == (x))
+#endif
+
 template <typename T, int BM, int BN, int WGM, int WGN, int STAGES, bool CONV>
 __global__ __launch_bounds__(WGM* WGN * 64) void gemm2_kernel(const GemmArgs p) {
   constexpr bool F32 = sizeof(T) == 4;     // exact-f32 MFMA (v_mfma_f32_16x16x4_f32) on f32 operands
@@ -151,7 +164,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm2_kernel(const GemmArgs p) 
   };
   auto advance_k = [&]() { if (CONV) { cc += BKE; if (cc >= p.Cin) { cc = 0; ++tap; } } };
   auto stage_tile = [&](char* stage, int k0) {   // all pieces back to back (prologue)
-    if (p.debug == 1) return;
+    if (GEMM2_DBG(1)) return;
     int ky = 0, kx = 0;
     if (CONV) { ky = tap / ntx; kx = tap - ky * ntx; }
     [&]<int... PI>(std::integer_sequence<int, PI...>) { (stage_piece(std::integral_constant<int, PI>{}, stage, k0, ky, kx), ...); }
@@ -176,29 +189,54 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm2_kernel(const GemmArgs p) 
     const char* sw = stage + BM * 128;
     int ky = 0, kx = 0;
     if (CONV) { ky = tap / ntx; kx = tap - ky * ntx; }
-    if (p.debug == 1) do_stage = false;
+    if (GEMM2_DBG(1)) do_stage = false;
     constexpr int NGROUP = 2 * TN;
+    // one 16-byte fragment per lane and tile: 8 bf16 (one 16x16x32 MFMA) or 4 f32 (four 16x16x4
+    // MFMAs; the k order inside the group is permuted alike for both operands)
+    typedef typename std::conditional<F32, f32x4_t, bf16x8_t>::type frag_t;
+    // The two K halves (g) of the tile use separate fragment registers and the reads of half 1 are
+    // issued before the MFMAs of half 0 (sched_barriers pin that order): left to itself hipcc
+    // re-uses one register quad and emits "ds_read; s_waitcnt lgkmcnt(0); 4 MFMAs" ten times per
+    // tile, i.e. an exposed LDS latency every 64 MFMA cycles.
+    // Measured (same box, experiments/gemm_bench.py): +3-9 % on the 8-wave 128x320 tile, -35 % on the 4-wave
+    // 128x160 tile (two workgroups per CU: its waves interleave best at the compiler's fine grain), so 8 waves only.
+    constexpr bool PREFETCH = !INTERLEAVE_DMA && NW == 8 && (TM + TN) <= 9;
+    frag_t xf[2][TM], wf[2][TN];
+    auto load_frags = [&](int g) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) xf[g][i] = *reinterpret_cast<const frag_t*>(sa + swz2(wm * WTM + i * 16 + r16, 4 * g + q4));
+#pragma unroll
+      for (int j = 0; j < TN; ++j) wf[g][j] = *reinterpret_cast<const frag_t*>(sw + swz2(wn * WTN + j * 16 + r16, 4 * g + q4));
+    };
+    if constexpr (PREFETCH) {
+      load_frags(0);
+      __builtin_amdgcn_sched_barrier(0);
+      load_frags(1);
+      // one scheduling region = [reads of half 1 | MFMAs of half 0], pinned to "1 ds_read, then a few MFMAs":
+      // the reads ride under the matrix pipe instead of bursting (a burst of all 18 reads with every wave of
+      // the workgroup behind the same barrier measured 40 % slower on the 4-wave tile)
+      constexpr int NRD = TM + TN, NMF = TM * TN * (F32 ? 4 : 1), PER = NMF / NRD;
+#pragma unroll
+      for (int r = 0; r < NRD; ++r) {
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);     // DS read
+        __builtin_amdgcn_sched_group_barrier(0x008, PER, 0);   // MFMA
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, NMF - PER * NRD, 0);
+    }
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
-      // one 16-byte fragment per lane and tile: 8 bf16 (one 16x16x32 MFMA) or 4 f32 (four 16x16x4
-      // MFMAs; the k order inside the group is permuted alike for both operands)
-      typedef typename std::conditional<F32, f32x4_t, bf16x8_t>::type frag_t;
-      frag_t xf[TM], wf[TN];
-#pragma unroll
-      for (int j = 0; j < TN; ++j) wf[j] = *reinterpret_cast<const frag_t*>(sw + swz2(wn * WTN + j * 16 + r16, 4 * g + q4));
-#pragma unroll
-      for (int i = 0; i < TM; ++i) xf[i] = *reinterpret_cast<const frag_t*>(sa + swz2(wm * WTM + i * 16 + r16, 4 * g + q4));
+      if constexpr (!PREFETCH) load_frags(g);
       [&]<int... J>(std::integer_sequence<int, J...>) {
         ([&] {
           constexpr int j = J;
-          if (p.debug != 2) {
+          if (!GEMM2_DBG(2)) {
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
               if constexpr (F32) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[j][e], xf[i][e], acc[j][i], 0, 0, 0);
+                for (int e = 0; e < 4; ++e) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[g][j][e], xf[g][i][e], acc[j][i], 0, 0, 0);
               } else {
-                acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc[j][i], 0, 0, 0);
+                acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[g][j], xf[g][i], acc[j][i], 0, 0, 0);
               }
             }
           }
@@ -211,6 +249,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm2_kernel(const GemmArgs p) 
           }(std::make_integer_sequence<int, NPIECE>{});
         }(), ...);
       }(std::make_integer_sequence<int, TN>{});
+      if constexpr (PREFETCH) __builtin_amdgcn_sched_barrier(0);
     }
     if (do_stage) advance_k();
   };
