@@ -112,26 +112,36 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm2_kernel(const GemmArgs p) 
     const int n = min(n0 + row, p.N - 1);
     wsrc[i] = W + (size_t)n * p.ldw + (cl ^ ((row >> 1) & 7)) * EPC;
   }
-  const T* asrc[A_INS];  // dense: row pointer (+ swizzled chunk); conv: image base (+ chunk)
-  int ay[A_INS], ax[A_INS];   // conv: top-left input coordinate of the 3x3 window (upsampled grid)
+  // A sources.  Dense: row pointer (+ swizzled chunk).  Conv: pointer to the top-left tap of the pixel's window
+  // (may lie outside the image) + a bit mask of the taps that are inside: per K-tile the gather address is then
+  // that pointer plus a wave-uniform (scalar) offset (ky*W + kx)*Cin + c0, and padding taps select the zero page.
+  // (The gathered nearest-2x form is not built here: launch_gemm2 sends it to gemm_conv.hip; the models use the
+  // phase form.)
+  const T* asrc[A_INS];
+  unsigned amask[A_INS];
 #pragma unroll
   for (int i = 0; i < A_INS; ++i) {
     const int row = min(wave + NW * i, A_PIECES - 1) * 8 + rr;
     const int m = min(m0 + row, p.M - 1);
     const int coff = (cl ^ ((row >> 1) & 7)) * EPC;
+    amask[i] = 0;
     if (CONV) {
       const int hw = p.Ho * p.Wo;
       const int n_img = m / hw, rem = m - n_img * hw;
       const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
-      ay[i] = oy * p.stride - (phase_up ? 1 - py : p.pad);
-      ax[i] = ox * p.stride - (phase_up ? 1 - px : p.pad);
-      asrc[i] = A + (size_t)n_img * p.H * p.Wd * p.Cin + coff;
+      const int ay = oy * p.stride - (phase_up ? 1 - py : p.pad);
+      const int ax = ox * p.stride - (phase_up ? 1 - px : p.pad);
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+          if (ky < ntx && kx < ntx && (unsigned)(ay + ky) < (unsigned)p.H && (unsigned)(ax + kx) < (unsigned)p.Wd)
+            amask[i] |= 1u << (ky * ntx + kx);
+      asrc[i] = A + ((long long)n_img * p.H * p.Wd + (long long)ay * p.Wd + ax) * p.Cin + coff;
     } else {
       asrc[i] = A + (size_t)m * p.lda + coff;
-      ay[i] = ax[i] = 0;
     }
   }
-  const int Hin = p.H << p.ups, Win = p.Wd << p.ups;
   const T* zsrc = reinterpret_cast<const T*>(g_zero_page) + cl * EPC;
 
   // this workgroup's K-tiles: [kt_begin, kt_begin + nk)
@@ -149,9 +159,8 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm2_kernel(const GemmArgs p) 
       if (A_PIECES % NW != 0 && i == A_INS - 1 && wave + NW * i >= A_PIECES) return;
       const T* g;
       if (CONV) {
-        const int iy = ay[i] + ky, ix = ax[i] + kx;
-        const bool ok = (unsigned)iy < (unsigned)Hin && (unsigned)ix < (unsigned)Win;
-        g = ok ? asrc[i] + ((size_t)(iy >> p.ups) * p.Wd + (ix >> p.ups)) * p.Cin + cc : zsrc;
+        const int delta = __builtin_amdgcn_readfirstlane((ky * p.Wd + kx) * p.Cin + cc);   // wave-uniform
+        g = ((amask[i] >> __builtin_amdgcn_readfirstlane(ky * ntx + kx)) & 1u) ? asrc[i] + delta : zsrc;
       } else {
         g = asrc[i] + k0;
       }
@@ -565,6 +574,7 @@ int gemm2_choose_tile(int M, int N, int K, int batch, int mode, size_t ws_bytes,
 
 template <typename T>
 static int launch_gemm2_t(GemmArgs& a, int batch, bool conv, int mode, hipStream_t st) {
+  if (conv && a.ups) return -1;   // gathered nearest-2x conv: gemm_conv.hip (the models use the phase form)
   if ((a.ldr % 4) != 0 || (a.R && ((uintptr_t)a.R % 16) != 0)) return -1;
   if (sizeof(T) == 2 && !a.out_f32 && ((a.ldc % 8) != 0 || (a.sC % 8) != 0)) return -1;   // 16-byte row-segment stores
   if (sizeof(T) == 4 && ((a.ldc % 4) != 0 || (a.sC % 4) != 0)) return -1;
