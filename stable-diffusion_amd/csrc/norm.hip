@@ -8,7 +8,7 @@
 // GroupNorm stats: grid (nblk, B), 256 threads.  A block walks a contiguous range of pixels of
 // image n; thread t owns channel-vector cv = t % tpp (+ i*tpp for i < nchunk) and pixel lane
 // t / tpp, so the channel (hence the group) of every register accumulator is fixed.
-// Per-block partial sums go to ws[n][blk][32][2] (double); gn_apply finishes the reduction.
+// Per-block partial sums go to ws[n][blk][32][2] (double); every gn_apply block finishes the reduction.
 // ---------------------------------------------------------------------------------------------
 constexpr int GN_THREADS = 256;
 constexpr int GN_MAXCHUNK = 4;
@@ -75,45 +75,38 @@ __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const T* __restric
   }
 }
 
-// GroupNorm finalize: grid B, 256 threads = 32 groups x 8 lanes.  Reduces the per-block partials of
-// image n into mean / rstd per group: fin[n][g] = {mean, rstd} (f32).  Each lane sums every 8th
-// block (its loads are independent, so they overlap), then a fixed-order shuffle tree: deterministic.
-// (A single thread per group walking up to 64 dependent loads took 14 us per GroupNorm.)
-__global__ __launch_bounds__(256) void gn_finalize_kernel(const double* __restrict__ ws, float* __restrict__ fin,
-                                                          int nblk_stats, int HW, int cpg, float eps) {
-  const int n = blockIdx.x, t = threadIdx.x;
-  const int g = t >> 3, sub = t & 7;
-  double ss = 0.0, qq = 0.0;
-  for (int b = sub; b < nblk_stats; b += 8) {
-    const double* src = ws + (((size_t)n * nblk_stats + b) * 32 + g) * 2;
-    ss += src[0]; qq += src[1];
-  }
-#pragma unroll
-  for (int o = 4; o > 0; o >>= 1) { ss += __shfl_xor(ss, o, 64); qq += __shfl_xor(qq, o, 64); }
-  if (sub == 0) {
-    const double cnt = (double)HW * cpg;
-    const double mean = ss / cnt;
-    double var = qq / cnt - mean * mean;
-    if (var < 0.0) var = 0.0;
-    fin[((size_t)n * 32 + g) * 2 + 0] = (float)mean;
-    fin[((size_t)n * 32 + g) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
-  }
-}
-
-// GroupNorm apply (+ optional SiLU): grid (nblk2, B); pure streaming pass, 16-byte vectors.
+// GroupNorm apply (+ optional SiLU): grid (nblk2, B); streaming pass, 16-byte vectors.  Every block first
+// finishes the statistics of its image itself: 256 threads = 32 groups x 8 lanes, each lane sums every 8th
+// per-block partial (independent loads from L2), then a fixed-order shuffle tree -- the same order in every
+// block and every run, so results are deterministic.  (As a kernel of its own this step was 4.7 us per
+// GroupNorm, 1.2 % of the bench's GPU time.)
 template <typename T, typename TO>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, TO* __restrict__ y,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                       const float* __restrict__ fin, int HW, int C, int silu,
-                                                       int pix_per_blk) {
+                                                       const double* __restrict__ ws, int nblk_stats, float eps, int HW,
+                                                       int C, int silu, int pix_per_blk) {
   constexpr int V = 16 / sizeof(T);
   __shared__ float s_mean[32], s_rstd[32];
   const int n = blockIdx.y;
   const int t = threadIdx.x;
   const int cpg = C / 32;
-  if (t < 32) {
-    s_mean[t] = fin[((size_t)n * 32 + t) * 2 + 0];
-    s_rstd[t] = fin[((size_t)n * 32 + t) * 2 + 1];
+  {
+    const int g = t >> 3, sub = t & 7;
+    double ss = 0.0, qq = 0.0;
+    for (int b = sub; b < nblk_stats; b += 8) {
+      const double* src = ws + (((size_t)n * nblk_stats + b) * 32 + g) * 2;
+      ss += src[0]; qq += src[1];
+    }
+#pragma unroll
+    for (int o = 4; o > 0; o >>= 1) { ss += __shfl_xor(ss, o, 64); qq += __shfl_xor(qq, o, 64); }
+    if (sub == 0) {
+      const double cnt = (double)HW * cpg;
+      const double mean = ss / cnt;
+      double var = qq / cnt - mean * mean;
+      if (var < 0.0) var = 0.0;
+      s_mean[g] = (float)mean;
+      s_rstd[g] = (float)(1.0 / sqrt(var + (double)eps));
+    }
   }
   __syncthreads();
   const int vpp = C / V;  // vectors per pixel
@@ -244,7 +237,7 @@ static int gn_geometry(int C, int V, int* tpp, int* nchunk) {
   return 0;
 }
 
-// workspace: per-block partials [B][64][32][2] f64, then finalized {mean, rstd} [B][32][2] f32
+// workspace: per-block partials [B][64][32][2] f64 (sized as before: the tail once held the finalized statistics)
 extern "C" size_t sdamd_groupnorm_ws_bytes(int B) { return (size_t)B * (64 * 32 * 2 * sizeof(double) + 32 * 2 * sizeof(float)); }
 
 extern "C" int sdamd_groupnorm_nhwc(const void* x, void* y, const float* gamma, const float* beta, void* ws, int B,
@@ -277,9 +270,6 @@ extern "C" int sdamd_groupnorm_nhwc(const void* x, void* y, const float* gamma, 
     gn_stats_kernel<float><<<grid, GN_THREADS, lds, st>>>((const float*)x, (double*)ws, HW, C, tpp, nchunk, ppb);
   }
   SD_LAUNCH_CHECK("gn_stats");
-  float* fin = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + (size_t)B * 64 * 32 * 2 * sizeof(double));
-  gn_finalize_kernel<<<B, 256, 0, st>>>((const double*)ws, fin, nblk, HW, C / 32, eps);
-  SD_LAUNCH_CHECK("gn_finalize");
   // apply: ~4K vectors (64 KB) per block, but keep >= ~1024 blocks in flight
   int vpp = C / V;
   long long total_vec = (long long)B * HW * vpp;
@@ -290,11 +280,11 @@ extern "C" int sdamd_groupnorm_nhwc(const void* x, void* y, const float* gamma, 
   int nblk2 = (HW + ppb2 - 1) / ppb2;
   dim3 grid2(nblk2, B);
   if (dtype == SDAMD_BF16)
-    gn_apply_kernel<bf16_t, bf16_t><<<grid2, 256, 0, st>>>((const bf16_t*)x, (bf16_t*)y, gamma, beta, fin, HW, C, silu, ppb2);
+    gn_apply_kernel<bf16_t, bf16_t><<<grid2, 256, 0, st>>>((const bf16_t*)x, (bf16_t*)y, gamma, beta, (const double*)ws, nblk, eps, HW, C, silu, ppb2);
   else if (out_dtype == SDAMD_BF16)
-    gn_apply_kernel<float, bf16_t><<<grid2, 256, 0, st>>>((const float*)x, (bf16_t*)y, gamma, beta, fin, HW, C, silu, ppb2);
+    gn_apply_kernel<float, bf16_t><<<grid2, 256, 0, st>>>((const float*)x, (bf16_t*)y, gamma, beta, (const double*)ws, nblk, eps, HW, C, silu, ppb2);
   else
-    gn_apply_kernel<float, float><<<grid2, 256, 0, st>>>((const float*)x, (float*)y, gamma, beta, fin, HW, C, silu, ppb2);
+    gn_apply_kernel<float, float><<<grid2, 256, 0, st>>>((const float*)x, (float*)y, gamma, beta, (const double*)ws, nblk, eps, HW, C, silu, ppb2);
   SD_LAUNCH_CHECK("gn_apply");
   return 0;
 }
