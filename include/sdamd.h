@@ -64,6 +64,12 @@ size_t sdamd_groupnorm_ws_bytes(int B);
 int sdamd_groupnorm_nhwc(const void* x, void* y, const float* gamma, const float* beta, void* ws,
                          int B, int HW, int C, float eps, int silu, int dtype, int out_dtype,
                          void* stream);
+/* GroupNorm(32, C1+C2) of torch.cat((x1, x2), dim=channel) without materialising the concat: the
+ * skip connections of the UNet's up path, diffusion.py:279 followed by :26-28 of the next
+ * UNET_ResidualBlock.  x1 [B][HW][C1], x2 [B][HW][C2], y [B][HW][C1+C2]. */
+int sdamd_groupnorm_nhwc_cat(const void* x1, const void* x2, int C1, int C2, void* y,
+                             const float* gamma, const float* beta, void* ws, int B, int HW,
+                             float eps, int silu, int dtype, int out_dtype, void* stream);
 /* nn.LayerNorm(C): diffusion.py:109,117,126; clip.py:54,63,95; dtypes as for groupnorm */
 int sdamd_layernorm(const void* x, void* y, const float* gamma, const float* beta, int rows, int C,
                     float eps, int dtype, int out_dtype, void* stream);
@@ -89,6 +95,10 @@ int sdamd_cast(const void* src, void* dst, long long n, int src_dtype, int dst_d
  * operand (1x1 skip convs diffusion.py:18,42; conv_output diffusion.py:85,140), so that bf16
  * MFMA does not round the trunk (no reference counterpart: the reference computes these in f32) */
 int sdamd_split_hilo(const float* src, void* dst, long long rows, int K, void* stream);
+/* same over the column concat [src1 (K1) | src2 (K2)] (skip concat diffusion.py:279 feeding the
+ * 1x1 residual_layer diffusion.py:42): dst [rows][2*(K1+K2)] */
+int sdamd_split_hilo_cat(const float* src1, const float* src2, void* dst, long long rows, int K1,
+                         int K2, void* stream);
 /* F.silu on an f32 vector (diffusion.py:32) */
 int sdamd_silu(const float* src, float* dst, long long n, void* stream);
 int sdamd_transpose(const void* src, void* dst, int batch, int rows, int cols, int ld_src,

@@ -22,6 +22,7 @@ SIGNATURES = {
     "sdamd_gather_row": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
     "sdamd_groupnorm_ws_bytes": (_sz, [_i]),
     "sdamd_groupnorm_nhwc": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _i, _i, _vp]),
+    "sdamd_groupnorm_nhwc_cat": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _f, _i, _i, _i, _vp]),
     "sdamd_layernorm": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _i, _i, _vp]),
     "sdamd_softmax_rows": (_i, [_vp, _vp, _i, _i, _f, _i, _vp]),
     "sdamd_geglu": (_i, [_vp, _vp, _ll, _i, _i, _vp]),
@@ -32,6 +33,7 @@ SIGNATURES = {
     "sdamd_nhwc_to_nchw": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "sdamd_cast": (_i, [_vp, _vp, _ll, _i, _i, _vp]),
     "sdamd_split_hilo": (_i, [_vp, _vp, _ll, _i, _vp]),
+    "sdamd_split_hilo_cat": (_i, [_vp, _vp, _vp, _ll, _i, _i, _vp]),
     "sdamd_silu": (_i, [_vp, _vp, _ll, _vp]),
     "sdamd_transpose": (_i, [_vp, _vp, _i, _i, _i, _i, _ll, _ll, _i, _vp]),
     "sdamd_image_to_uint8": (_i, [_vp, _vp, _i, _i, _vp]),

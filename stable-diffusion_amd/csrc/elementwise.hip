@@ -170,14 +170,17 @@ __global__ __launch_bounds__(256) void cast_kernel(const TI* __restrict__ src, T
 // hi/lo split of an f32 matrix into two bf16 terms: dst [rows][2K] = [bf16(x) | bf16(x - bf16(x))].
 // A GEMM over the doubled K against [W | W] then sees the f32 operand to ~2^-17 (used where the
 // un-normalised residual trunk itself is a GEMM operand: 1x1 skip convs and conv_output).
-__global__ __launch_bounds__(256) void split_hilo_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, size_t rows,
-                                                         int K) {
+// src2 != null: the matrix is the column concat [src (K1 columns) | src2 (K - K1)], never materialised.
+__global__ __launch_bounds__(256) void split_hilo_kernel(const float* __restrict__ src, const float* __restrict__ src2, int K1,
+                                                         bf16_t* __restrict__ dst, size_t rows, int K) {
   const int vpr = K / 4;
   const size_t total = rows * vpr;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
     const size_t r = i / vpr;
     const int cv = (int)(i - r * vpr);
-    const f32x4_t x = *reinterpret_cast<const f32x4_t*>(src + r * K + (size_t)cv * 4);
+    const int c0 = cv * 4;
+    const float* sp = !src2 ? src + r * K + c0 : c0 < K1 ? src + r * K1 + c0 : src2 + r * (K - K1) + (c0 - K1);
+    const f32x4_t x = *reinterpret_cast<const f32x4_t*>(sp);
     float hi[4], lo[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) { hi[j] = bf2f(f2bf(x[j])); lo[j] = x[j] - hi[j]; }
@@ -396,8 +399,17 @@ extern "C" int sdamd_cast(const void* src, void* dst, long long n, int src_dtype
 
 extern "C" int sdamd_split_hilo(const float* src, void* dst, long long rows, int K, void* stream) {
   SD_CHECK(rows > 0 && K > 0 && K % 4 == 0, "split_hilo: bad shape rows=%lld K=%d", rows, K);
-  split_hilo_kernel<<<grid_for((size_t)rows * (K / 4)), 256, 0, (hipStream_t)stream>>>(src, (bf16_t*)dst, (size_t)rows, K);
+  split_hilo_kernel<<<grid_for((size_t)rows * (K / 4)), 256, 0, (hipStream_t)stream>>>(src, nullptr, 0, (bf16_t*)dst, (size_t)rows, K);
   SD_LAUNCH_CHECK("split_hilo");
+  return 0;
+}
+
+extern "C" int sdamd_split_hilo_cat(const float* src1, const float* src2, void* dst, long long rows, int K1, int K2, void* stream) {
+  SD_CHECK(rows > 0 && K1 > 0 && K2 > 0 && K1 % 4 == 0 && K2 % 4 == 0, "split_hilo_cat: bad shape rows=%lld K1=%d K2=%d", rows, K1, K2);
+  SD_CHECK(src1 && src2, "split_hilo_cat: null source");
+  split_hilo_kernel<<<grid_for((size_t)rows * ((K1 + K2) / 4)), 256, 0, (hipStream_t)stream>>>(src1, src2, K1, (bf16_t*)dst, (size_t)rows,
+                                                                                               K1 + K2);
+  SD_LAUNCH_CHECK("split_hilo_cat");
   return 0;
 }
 

@@ -14,8 +14,9 @@ constexpr int GN_THREADS = 256;
 constexpr int GN_MAXCHUNK = 4;
 
 template <typename T>
-__global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const T* __restrict__ x, double* __restrict__ ws,
-                                                              int HW, int C, int tpp, int nchunk, int pix_per_blk) {
+__global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const T* __restrict__ x, const T* __restrict__ x2, int C1,
+                                                              double* __restrict__ ws, int HW, int C, int tpp, int nchunk,
+                                                              int pix_per_blk) {
   constexpr int V = 16 / sizeof(T);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   double* part = reinterpret_cast<double*>(smem);  // [pif][C][2]
@@ -31,14 +32,22 @@ __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const T* __restric
 #pragma unroll
     for (int j = 0; j < V; ++j) { s[i][j] = 0.0; q[i][j] = 0.0; }
   if (pl < pif) {
-    const T* base = x + (size_t)n * HW * C;
+    // x2 != null: the tensor is the channel concat [x (C1 channels) | x2 (C - C1)] of two NHWC tensors that is
+    // never materialised (UNet skip connections); a thread's channel vectors are fixed, so is their source
+    const T* src[GN_MAXCHUNK];
+    int rs[GN_MAXCHUNK];
+#pragma unroll
+    for (int i = 0; i < GN_MAXCHUNK; ++i) {
+      const int c0 = (cvt + i * tpp) * V;
+      if (x2 && c0 >= C1) { rs[i] = C - C1; src[i] = x2 + (size_t)n * HW * rs[i] + (c0 - C1); }
+      else { rs[i] = x2 ? C1 : C; src[i] = x + (size_t)n * HW * rs[i] + c0; }
+    }
     for (int p = p0 + pl; p < p1; p += pif) {
-      const T* row = base + (size_t)p * C;
 #pragma unroll
       for (int i = 0; i < GN_MAXCHUNK; ++i) {
         if (i < nchunk) {
           float v[V];
-          load_vec<T>(row + (size_t)(cvt + i * tpp) * V, v);
+          load_vec<T>(src[i] + (size_t)p * rs[i], v);
 #pragma unroll
           for (int j = 0; j < V; ++j) { double d = (double)v[j]; s[i][j] += d; q[i][j] += d * d; }
         }
@@ -81,8 +90,9 @@ __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const T* __restric
 // block and every run, so results are deterministic.  (As a kernel of its own this step was 4.7 us per
 // GroupNorm, 1.2 % of the bench's GPU time.)
 template <typename T, typename TO>
-__global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, TO* __restrict__ y,
-                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+__global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, const T* __restrict__ x2, int C1,
+                                                       TO* __restrict__ y, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta,
                                                        const double* __restrict__ ws, int nblk_stats, float eps, int HW,
                                                        int C, int silu, int pix_per_blk) {
   constexpr int V = 16 / sizeof(T);
@@ -119,9 +129,11 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
   int p = p0 + t / vpp, cv = t % vpp;
   for (int i = t; i < nvec; i += 256) {
     const size_t off = img + (size_t)p * C + (size_t)cv * V;
-    float v[V];
-    load_vec<T>(x + off, v);
     const int c0 = cv * V;
+    float v[V];
+    if (!x2) load_vec<T>(x + off, v);
+    else if (c0 < C1) load_vec<T>(x + ((size_t)n * HW + p) * C1 + c0, v);
+    else load_vec<T>(x2 + ((size_t)n * HW + p) * (C - C1) + (c0 - C1), v);
     f32x4_t gm[V / 4], bt[V / 4];
 #pragma unroll
     for (int k = 0; k < V / 4; ++k) {
@@ -240,9 +252,10 @@ static int gn_geometry(int C, int V, int* tpp, int* nchunk) {
 // workspace: per-block partials [B][64][32][2] f64 (sized as before: the tail once held the finalized statistics)
 extern "C" size_t sdamd_groupnorm_ws_bytes(int B) { return (size_t)B * (64 * 32 * 2 * sizeof(double) + 32 * 2 * sizeof(float)); }
 
-extern "C" int sdamd_groupnorm_nhwc(const void* x, void* y, const float* gamma, const float* beta, void* ws, int B,
-                                    int HW, int C, float eps, int silu, int dtype, int out_dtype, void* stream) {
+static int groupnorm_impl(const void* x, const void* x2, int C1, void* y, const float* gamma, const float* beta, void* ws, int B,
+                          int HW, int C, float eps, int silu, int dtype, int out_dtype, void* stream) {
   const int V = dtype == SDAMD_BF16 ? 8 : 4;
+  SD_CHECK(!x2 || (C1 > 0 && C1 < C && C1 % V == 0), "groupnorm_cat: bad split C1=%d of C=%d", C1, C);
   SD_CHECK((dtype == SDAMD_BF16 || dtype == SDAMD_F32) && (out_dtype == SDAMD_BF16 || out_dtype == SDAMD_F32) &&
            !(dtype == SDAMD_BF16 && out_dtype == SDAMD_F32), "groupnorm: unsupported dtypes in=%d out=%d", dtype, out_dtype);
   SD_CHECK(C % 32 == 0 && C % V == 0, "groupnorm: C=%d must be a multiple of 32 and of the 16-byte vector", C);
@@ -264,10 +277,10 @@ extern "C" int sdamd_groupnorm_nhwc(const void* x, void* y, const float* gamma, 
   dim3 grid(nblk, B);
   if (dtype == SDAMD_BF16) {
     if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)gn_stats_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    gn_stats_kernel<bf16_t><<<grid, GN_THREADS, lds, st>>>((const bf16_t*)x, (double*)ws, HW, C, tpp, nchunk, ppb);
+    gn_stats_kernel<bf16_t><<<grid, GN_THREADS, lds, st>>>((const bf16_t*)x, (const bf16_t*)x2, C1, (double*)ws, HW, C, tpp, nchunk, ppb);
   } else {
     if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)gn_stats_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    gn_stats_kernel<float><<<grid, GN_THREADS, lds, st>>>((const float*)x, (double*)ws, HW, C, tpp, nchunk, ppb);
+    gn_stats_kernel<float><<<grid, GN_THREADS, lds, st>>>((const float*)x, (const float*)x2, C1, (double*)ws, HW, C, tpp, nchunk, ppb);
   }
   SD_LAUNCH_CHECK("gn_stats");
   // apply: ~4K vectors (64 KB) per block, but keep >= ~1024 blocks in flight
@@ -280,13 +293,25 @@ extern "C" int sdamd_groupnorm_nhwc(const void* x, void* y, const float* gamma, 
   int nblk2 = (HW + ppb2 - 1) / ppb2;
   dim3 grid2(nblk2, B);
   if (dtype == SDAMD_BF16)
-    gn_apply_kernel<bf16_t, bf16_t><<<grid2, 256, 0, st>>>((const bf16_t*)x, (bf16_t*)y, gamma, beta, (const double*)ws, nblk, eps, HW, C, silu, ppb2);
+    gn_apply_kernel<bf16_t, bf16_t><<<grid2, 256, 0, st>>>((const bf16_t*)x, (const bf16_t*)x2, C1, (bf16_t*)y, gamma, beta, (const double*)ws, nblk, eps, HW, C, silu, ppb2);
   else if (out_dtype == SDAMD_BF16)
-    gn_apply_kernel<float, bf16_t><<<grid2, 256, 0, st>>>((const float*)x, (bf16_t*)y, gamma, beta, (const double*)ws, nblk, eps, HW, C, silu, ppb2);
+    gn_apply_kernel<float, bf16_t><<<grid2, 256, 0, st>>>((const float*)x, (const float*)x2, C1, (bf16_t*)y, gamma, beta, (const double*)ws, nblk, eps, HW, C, silu, ppb2);
   else
-    gn_apply_kernel<float, float><<<grid2, 256, 0, st>>>((const float*)x, (float*)y, gamma, beta, (const double*)ws, nblk, eps, HW, C, silu, ppb2);
+    gn_apply_kernel<float, float><<<grid2, 256, 0, st>>>((const float*)x, (const float*)x2, C1, (float*)y, gamma, beta, (const double*)ws, nblk, eps, HW, C, silu, ppb2);
   SD_LAUNCH_CHECK("gn_apply");
   return 0;
+}
+
+extern "C" int sdamd_groupnorm_nhwc(const void* x, void* y, const float* gamma, const float* beta, void* ws, int B,
+                                    int HW, int C, float eps, int silu, int dtype, int out_dtype, void* stream) {
+  return groupnorm_impl(x, nullptr, 0, y, gamma, beta, ws, B, HW, C, eps, silu, dtype, out_dtype, stream);
+}
+
+extern "C" int sdamd_groupnorm_nhwc_cat(const void* x1, const void* x2, int C1, int C2, void* y, const float* gamma,
+                                        const float* beta, void* ws, int B, int HW, float eps, int silu, int dtype,
+                                        int out_dtype, void* stream) {
+  SD_CHECK(x1 && x2 && C1 > 0 && C2 > 0, "groupnorm_cat: null source or empty half");
+  return groupnorm_impl(x1, x2, C1, y, gamma, beta, ws, B, HW, C1 + C2, eps, silu, dtype, out_dtype, stream);
 }
 
 extern "C" int sdamd_layernorm(const void* x, void* y, const float* gamma, const float* beta, int rows, int C, float eps,

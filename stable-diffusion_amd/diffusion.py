@@ -42,13 +42,20 @@ class UNET_ResidualBlock(engine.HipModule):
         return ops.gemm(time_silu, w, b).reshape(-1)
 
     def run(self, x, tbias):
-        """x NHWC in the trunk dtype; tbias f32 [Cout].  Operands of the convs are compute dtype."""
+        """x NHWC in the trunk dtype, or a pair (a, b) standing for their channel concat (skip connection of
+        the up path); tbias f32 [Cout].  Operands of the convs are compute dtype."""
         dt = self.compute_dtype
-        h = engine.groupnorm(x, self.groupnorm_feature, silu=True, out_dtype=dt)
+        x2 = None
+        if isinstance(x, tuple):
+            if dt == torch.bfloat16 and x[0].dtype == torch.float32:
+                x, x2 = x       # f32 trunk halves: GroupNorm and the hi|lo split read both sources, no concat pass
+            else:
+                x = ops.concat_channels(*x)
+        h = engine.groupnorm(x, self.groupnorm_feature, silu=True, out_dtype=dt, x2=x2)
         h = engine.conv3x3(h, self.conv_feature, bias=tbias)
         h = engine.groupnorm(h, self.groupnorm_merged, silu=True)
         skip = x if isinstance(self.residual_layer, nn.Identity) else \
-            engine.conv1x1(x, self.residual_layer, out_dtype=x.dtype, compute_dtype=dt)
+            engine.conv1x1(x, self.residual_layer, out_dtype=x.dtype, compute_dtype=dt, x2=x2)
         return engine.conv3x3(h, self.conv_merged, residual=skip)
 
     def forward(self, feature, time):
@@ -212,7 +219,7 @@ class UNET(engine.HipModule):
             skips.append(x)
         x = self._stage(self.bottleneck, x, kv, tbias)
         for stage in self.decoders:
-            x = self._stage(stage, ops.concat_channels(x, skips.pop()), kv, tbias)
+            x = self._stage(stage, (x, skips.pop()), kv, tbias)   # torch.cat((x, skip), dim=1), diffusion.py:279: never materialised
         return x
 
     def _stage(self, stage, x, kv, tbias):

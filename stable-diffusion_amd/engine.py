@@ -128,14 +128,16 @@ def linear_geglu(x, lin):
     return ops.geglu(linear(x, lin))
 
 
-def conv1x1(x, conv, residual=None, out_dtype=None, compute_dtype=None):
+def conv1x1(x, conv, residual=None, out_dtype=None, compute_dtype=None, x2=None):
     """x NHWC [B,H,W,C].  An f32 ``x`` under a bf16 compute dtype is the residual trunk itself:
-    it goes through the MFMA as two bf16 terms (hi|lo) against [W|W] instead of being rounded."""
+    it goes through the MFMA as two bf16 terms (hi|lo) against [W|W] instead of being rounded.
+    ``x2`` (that mode only): the operand is the channel concat [x | x2]."""
     if compute_dtype == torch.bfloat16 and x.dtype == torch.float32:
         w2 = packed(conv.weight, "c1x2", torch.bfloat16,
                     lambda w: w.reshape(w.shape[0], w.shape[1]).to(torch.bfloat16).repeat(1, 2).contiguous())
-        xs = ops.split_hilo(x)
+        xs = ops.split_hilo(x, x2)
         return ops.gemm(xs, w2, bias_of(conv), residual, ops.ACT_NONE, _out_f32(xs, residual, out_dtype))
+    assert x2 is None
     return ops.gemm(x, conv1x1_w(conv, x.dtype), bias_of(conv), residual, ops.ACT_NONE, _out_f32(x, residual, out_dtype))
 
 
@@ -183,8 +185,8 @@ def conv3x3_trunk(x, conv, compute_dtype, stride=1, upsample=False):
     return ops.conv3x3(x, conv3x3_w(conv, x.dtype), bias_of(conv), None, stride, 0, upsample)
 
 
-def groupnorm(x, gn, silu, out_dtype=None):
-    return ops.groupnorm(x, f32(gn.weight), f32(gn.bias), gn.eps, silu, out_dtype)
+def groupnorm(x, gn, silu, out_dtype=None, x2=None):
+    return ops.groupnorm(x, f32(gn.weight), f32(gn.bias), gn.eps, silu, out_dtype, x2)
 
 
 def layernorm(x, ln, out_dtype=None):

@@ -167,20 +167,32 @@ def gather_row(dst, table, step=0, step_ptr=None):
 
 
 # ------------------------------------------------------------------ norms
-def groupnorm(x, gamma, beta, eps, silu, out_dtype=None):
-    """x [B, ..., C] NHWC; 32 groups.  ``out_dtype`` (default: x's) may be bfloat16 for f32 input."""
+def groupnorm(x, gamma, beta, eps, silu, out_dtype=None, x2=None):
+    """x [B, ..., C] NHWC; 32 groups.  ``out_dtype`` (default: x's) may be bfloat16 for f32 input.
+    ``x2``: normalise the channel concat [x | x2] without materialising it."""
     _dev(x, gamma, beta)
     assert x.is_contiguous() and gamma.dtype == torch.float32 and beta.dtype == torch.float32
-    B, C = x.shape[0], x.shape[-1]
-    HW = x.numel() // (B * C)
+    B, C1 = x.shape[0], x.shape[-1]
+    HW = x.numel() // (B * C1)
+    C2 = 0
+    if x2 is not None:
+        _dev(x2)
+        assert x2.is_contiguous() and x2.dtype == x.dtype and x2.shape[:-1] == x.shape[:-1]
+        C2 = x2.shape[-1]
+    C = C1 + C2
     assert gamma.numel() == C and beta.numel() == C
     out_dtype = x.dtype if out_dtype is None else out_dtype
-    y = torch.empty(x.shape, dtype=out_dtype, device=x.device)
+    y = torch.empty(x.shape[:-1] + (C,), dtype=out_dtype, device=x.device)
     ws = _groupnorm_ws(B, x.device)
-    _timed(f"groupnorm_{_dt(x.dtype)}", x.numel() * (2 * x.element_size() + y.element_size()),   # stats read + apply read + write
-           lambda: _lib.check(_lib.lib().sdamd_groupnorm_nhwc(_p(x), _p(y), _p(gamma), _p(beta), _p(ws), B, HW, C, float(eps),
-                                                              int(silu), _code(x.dtype), _code(out_dtype), _stream())),
-           f"B{B} HW{HW} C{C}")
+    L = _lib.lib()
+    if x2 is None:
+        call = lambda: _lib.check(L.sdamd_groupnorm_nhwc(_p(x), _p(y), _p(gamma), _p(beta), _p(ws), B, HW, C, float(eps),
+                                                         int(silu), _code(x.dtype), _code(out_dtype), _stream()))
+    else:
+        call = lambda: _lib.check(L.sdamd_groupnorm_nhwc_cat(_p(x), _p(x2), C1, C2, _p(y), _p(gamma), _p(beta), _p(ws), B, HW,
+                                                             float(eps), int(silu), _code(x.dtype), _code(out_dtype), _stream()))
+    _timed(f"groupnorm_{_dt(x.dtype)}", B * HW * C * (2 * x.element_size() + y.element_size()),   # stats read + apply read + write
+           call, f"B{B} HW{HW} C{C}" + (" cat" if x2 is not None else ""))
     return y
 
 
@@ -281,15 +293,25 @@ def cast(x, dtype):
     return out
 
 
-def split_hilo(x):
-    """f32 [..., K] -> bf16 [..., 2K] = [bf16(x) | bf16(x - bf16(x))] (pair with weights [W | W])."""
+def split_hilo(x, x2=None):
+    """f32 [..., K] -> bf16 [..., 2K] = [bf16(x) | bf16(x - bf16(x))] (pair with weights [W | W]).
+    ``x2``: split the column concat [x | x2] without materialising it."""
     _dev(x)
     assert x.dtype == torch.float32 and x.is_contiguous()
-    K = x.shape[-1]
-    out = torch.empty(x.shape[:-1] + (2 * K,), dtype=torch.bfloat16, device=x.device)
-    _timed("split_hilo", x.numel() * 8,
-           lambda: _lib.check(_lib.lib().sdamd_split_hilo(_p(x), _p(out), x.numel() // K, K, _stream())),
-           f"rows{x.numel() // K} K{K}")
+    K1 = x.shape[-1]
+    rows = x.numel() // K1
+    if x2 is None:
+        out = torch.empty(x.shape[:-1] + (2 * K1,), dtype=torch.bfloat16, device=x.device)
+        _timed("split_hilo", x.numel() * 8,
+               lambda: _lib.check(_lib.lib().sdamd_split_hilo(_p(x), _p(out), rows, K1, _stream())), f"rows{rows} K{K1}")
+        return out
+    _dev(x2)
+    assert x2.dtype == torch.float32 and x2.is_contiguous() and x2.shape[:-1] == x.shape[:-1]
+    K2 = x2.shape[-1]
+    out = torch.empty(x.shape[:-1] + (2 * (K1 + K2),), dtype=torch.bfloat16, device=x.device)
+    _timed("split_hilo", rows * (K1 + K2) * 8,
+           lambda: _lib.check(_lib.lib().sdamd_split_hilo_cat(_p(x), _p(x2), _p(out), rows, K1, K2, _stream())),
+           f"rows{rows} K{K1}+{K2}")
     return out
 
 

@@ -126,6 +126,22 @@ def test_ddim_step_matches_golden():
     assert rel_l2(sm.add_noise(x, torch.tensor(780)).cpu(), g["add_noise_780"]) < 1e-6
 
 
+@pytest.mark.parametrize("C1,C2,HW", [(320, 320, 64), (1280, 640, 16), (640, 320, 100), (1280, 1280, 9)])
+def test_groupnorm_and_split_hilo_over_a_virtual_concat(C1, C2, HW):
+    """The skip-connection concat (diffusion.py:279) is never materialised: GroupNorm and the hi|lo split read the two
+    halves directly and must equal the same kernels on the real concat bit for bit."""
+    a, b = rnd("cat.a", (2, HW, C1), 2.0).to(DEV), rnd("cat.b", (2, HW, C2), 3.0).to(DEV)
+    g, bt = rnd("cat.g", (C1 + C2,)).to(DEV), rnd("cat.bt", (C1 + C2,)).to(DEV)
+    full = ops.concat_channels(a, b)
+    for out_dtype in (torch.float32, torch.bfloat16):
+        want = ops.groupnorm(full, g, bt, 1e-5, True, out_dtype)
+        got = ops.groupnorm(a, g, bt, 1e-5, True, out_dtype, x2=b)
+        assert got.shape == want.shape and torch.equal(got, want)
+    ab, bb = a.bfloat16(), b.bfloat16()
+    assert torch.equal(ops.groupnorm(ab, g, bt, 1e-5, False, x2=bb), ops.groupnorm(ops.concat_channels(ab, bb), g, bt, 1e-5, False))
+    assert torch.equal(ops.split_hilo(a, b), ops.split_hilo(full))
+
+
 def test_gather_row_and_silu():
     table = rnd("gather", (5, 96))
     dst = torch.empty(96, device=DEV)
