@@ -158,42 +158,50 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
 // LayerNorm over the last dim: one wave per row, the row lives in registers (C <= 64*5*V).
 // ---------------------------------------------------------------------------------------------
 constexpr int LN_MAXIT = 5;
-template <typename T, typename TO>
+// LPR lanes share one row (64 / LPR rows per wave): C = 320 f32 is 80 vectors = 16 lanes x 5, so a wave takes
+// 4 rows with every lane busy (one wave per row left 48 of 64 lanes idle on the second sweep: 3.7 -> 5 TB/s).
+template <typename T, typename TO, int LPR>
 __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x, TO* __restrict__ y,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         int rows, int C, float eps) {
   constexpr int V = 16 / sizeof(T);
-  const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= rows) return;
+  constexpr int RPW = 64 / LPR;
+  const int lane = threadIdx.x & 63, sub = lane % LPR;
+  const int row = (blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW + lane / LPR;
+  const bool live = row < rows;
   const int nvec = C / V;
-  const T* xr = x + (size_t)row * C;
+  const T* xr = x + (size_t)(live ? row : 0) * C;
   float v[LN_MAXIT][V];
   float sum = 0.f;
 #pragma unroll
   for (int i = 0; i < LN_MAXIT; ++i) {
-    int cv = lane + i * 64;
+    int cv = sub + i * LPR;
     if (cv < nvec) {
       load_vec<T>(xr + (size_t)cv * V, v[i]);
 #pragma unroll
       for (int j = 0; j < V; ++j) sum += v[i][j];
     }
   }
-  const float mean = wave_sum(sum) / (float)C;
+#pragma unroll
+  for (int o = LPR / 2; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+  const float mean = sum / (float)C;
   float sq = 0.f;
 #pragma unroll
   for (int i = 0; i < LN_MAXIT; ++i) {
-    int cv = lane + i * 64;
+    int cv = sub + i * LPR;
     if (cv < nvec) {
 #pragma unroll
       for (int j = 0; j < V; ++j) { float d = v[i][j] - mean; sq += d * d; }
     }
   }
-  const float rstd = 1.0f / sqrtf(wave_sum(sq) / (float)C + eps);
+#pragma unroll
+  for (int o = LPR / 2; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
+  const float rstd = 1.0f / sqrtf(sq / (float)C + eps);
+  if (!live) return;
   TO* yr = y + (size_t)row * C;
 #pragma unroll
   for (int i = 0; i < LN_MAXIT; ++i) {
-    int cv = lane + i * 64;
+    int cv = sub + i * LPR;
     if (cv < nvec) {
       float o[V];
 #pragma unroll
@@ -322,13 +330,17 @@ extern "C" int sdamd_layernorm(const void* x, void* y, const float* gamma, const
   SD_CHECK(C % V == 0 && C / V <= 64 * LN_MAXIT, "layernorm: unsupported C=%d", C);
   SD_CHECK(rows > 0, "layernorm: empty input");
   hipStream_t st = (hipStream_t)stream;
-  int grid = (rows + 3) / 4;
-  if (dtype == SDAMD_BF16)
-    layernorm_kernel<bf16_t, bf16_t><<<grid, 256, 0, st>>>((const bf16_t*)x, (bf16_t*)y, gamma, beta, rows, C, eps);
-  else if (out_dtype == SDAMD_BF16)
-    layernorm_kernel<float, bf16_t><<<grid, 256, 0, st>>>((const float*)x, (bf16_t*)y, gamma, beta, rows, C, eps);
-  else
-    layernorm_kernel<float, float><<<grid, 256, 0, st>>>((const float*)x, (float*)y, gamma, beta, rows, C, eps);
+  const int nvec = C / V;
+  const int lpr = nvec <= 16 * LN_MAXIT ? 16 : nvec <= 32 * LN_MAXIT ? 32 : 64;   // lanes per row
+#define LN_LAUNCH(TT, TTO, L)                                                                       \
+  layernorm_kernel<TT, TTO, L><<<(rows + 4 * (64 / L) - 1) / (4 * (64 / L)), 256, 0, st>>>((const TT*)x, (TTO*)y, gamma, beta, rows, C, eps)
+#define LN_DISPATCH(TT, TTO) \
+  { if (lpr == 16) LN_LAUNCH(TT, TTO, 16); else if (lpr == 32) LN_LAUNCH(TT, TTO, 32); else LN_LAUNCH(TT, TTO, 64); }
+  if (dtype == SDAMD_BF16) LN_DISPATCH(bf16_t, bf16_t)
+  else if (out_dtype == SDAMD_BF16) LN_DISPATCH(float, bf16_t)
+  else LN_DISPATCH(float, float)
+#undef LN_DISPATCH
+#undef LN_LAUNCH
   SD_LAUNCH_CHECK("layernorm");
   return 0;
 }
