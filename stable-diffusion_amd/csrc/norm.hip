@@ -13,10 +13,15 @@
 constexpr int GN_THREADS = 256;
 constexpr int GN_MAXCHUNK = 4;
 
-template <typename T>
+// NCHUNK is a template parameter and the pixel loop is unrolled so that every thread keeps >= 4 independent
+// 16-byte loads in flight: with one load per iteration the pass was latency-bound (the bf16-input pass took as
+// long as the f32 one although it moves half the bytes).
+template <typename T, int NCHUNK>
 __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const T* __restrict__ x, const T* __restrict__ x2, int C1,
-                                                              double* __restrict__ ws, int HW, int C, int tpp, int nchunk,
+                                                              double* __restrict__ ws, int HW, int C, int tpp,
                                                               int pix_per_blk) {
+  constexpr int nchunk = NCHUNK;
+  constexpr int UNR = NCHUNK >= 4 ? 1 : NCHUNK >= 2 ? 2 : 4;
   constexpr int V = 16 / sizeof(T);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   double* part = reinterpret_cast<double*>(smem);  // [pif][C][2]
@@ -42,15 +47,27 @@ __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const T* __restric
       if (x2 && c0 >= C1) { rs[i] = C - C1; src[i] = x2 + (size_t)n * HW * rs[i] + (c0 - C1); }
       else { rs[i] = x2 ? C1 : C; src[i] = x + (size_t)n * HW * rs[i] + c0; }
     }
-    for (int p = p0 + pl; p < p1; p += pif) {
+    int p = p0 + pl;
+    for (; p + (UNR - 1) * pif < p1; p += UNR * pif) {
+      float v[UNR][NCHUNK][V];
 #pragma unroll
-      for (int i = 0; i < GN_MAXCHUNK; ++i) {
-        if (i < nchunk) {
-          float v[V];
-          load_vec<T>(src[i] + (size_t)p * rs[i], v);
+      for (int u = 0; u < UNR; ++u)
 #pragma unroll
-          for (int j = 0; j < V; ++j) { double d = (double)v[j]; s[i][j] += d; q[i][j] += d * d; }
-        }
+        for (int i = 0; i < NCHUNK; ++i) load_vec<T>(src[i] + (size_t)(p + u * pif) * rs[i], v[u][i]);
+#pragma unroll
+      for (int u = 0; u < UNR; ++u)      // same accumulation order as the rolled loop: pixel-major
+#pragma unroll
+        for (int i = 0; i < NCHUNK; ++i)
+#pragma unroll
+          for (int j = 0; j < V; ++j) { double d = (double)v[u][i][j]; s[i][j] += d; q[i][j] += d * d; }
+    }
+    for (; p < p1; p += pif) {
+#pragma unroll
+      for (int i = 0; i < NCHUNK; ++i) {
+        float v[V];
+        load_vec<T>(src[i] + (size_t)p * rs[i], v);
+#pragma unroll
+        for (int j = 0; j < V; ++j) { double d = (double)v[j]; s[i][j] += d; q[i][j] += d * d; }
       }
     }
 #pragma unroll
@@ -127,13 +144,11 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
   const float inv_cpg = 1.0f / (float)cpg;
   const int dp = 256 / vpp, dcv = 256 % vpp;
   int p = p0 + t / vpp, cv = t % vpp;
-  for (int i = t; i < nvec; i += 256) {
-    const size_t off = img + (size_t)p * C + (size_t)cv * V;
-    const int c0 = cv * V;
-    float v[V];
-    if (!x2) load_vec<T>(x + off, v);
-    else if (c0 < C1) load_vec<T>(x + ((size_t)n * HW + p) * C1 + c0, v);
-    else load_vec<T>(x2 + ((size_t)n * HW + p) * (C - C1) + (c0 - C1), v);
+  auto src_of = [&](int pp, int c0) -> const T* {
+    if (!x2) return x + img + (size_t)pp * C + c0;
+    return c0 < C1 ? x + ((size_t)n * HW + pp) * C1 + c0 : x2 + ((size_t)n * HW + pp) * (C - C1) + (c0 - C1);
+  };
+  auto finish = [&](int pp, int c0, float (&v)[V]) {
     f32x4_t gm[V / 4], bt[V / 4];
 #pragma unroll
     for (int k = 0; k < V / 4; ++k) {
@@ -148,9 +163,25 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
       v[j] = silu ? silu_f(r) : r;
       if (++rem == cpg) { rem = 0; ++g; }
     }
-    store_n<TO, V>(y + off, v);
-    p += dp; cv += dcv;
-    if (cv >= vpp) { cv -= vpp; ++p; }
+    store_n<TO, V>(y + img + (size_t)pp * C + c0, v);
+  };
+  auto advance = [&]() { p += dp; cv += dcv; if (cv >= vpp) { cv -= vpp; ++p; } };
+  // 4 independent 16-byte loads in flight per thread (one per iteration left the pass latency-bound)
+  constexpr int UNR = 4;
+  int i = t;
+  for (; i + (UNR - 1) * 256 < nvec; i += UNR * 256) {
+    int pp[UNR], cc[UNR];
+    float v[UNR][V];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) { pp[u] = p; cc[u] = cv * V; load_vec<T>(src_of(p, cv * V), v[u]); advance(); }
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) finish(pp[u], cc[u], v[u]);
+  }
+  for (; i < nvec; i += 256) {
+    float v[V];
+    load_vec<T>(src_of(p, cv * V), v);
+    finish(p, cv * V, v);
+    advance();
   }
 }
 
@@ -283,13 +314,15 @@ static int groupnorm_impl(const void* x, const void* x2, int C1, void* y, const 
   nblk = (HW + ppb - 1) / ppb;
   hipStream_t st = (hipStream_t)stream;
   dim3 grid(nblk, B);
-  if (dtype == SDAMD_BF16) {
-    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)gn_stats_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    gn_stats_kernel<bf16_t><<<grid, GN_THREADS, lds, st>>>((const bf16_t*)x, (const bf16_t*)x2, C1, (double*)ws, HW, C, tpp, nchunk, ppb);
-  } else {
-    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)gn_stats_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    gn_stats_kernel<float><<<grid, GN_THREADS, lds, st>>>((const float*)x, (const float*)x2, C1, (double*)ws, HW, C, tpp, nchunk, ppb);
+#define GN_STATS(TT, NC)                                                                                               \
+  {                                                                                                                    \
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)gn_stats_kernel<TT, NC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    gn_stats_kernel<TT, NC><<<grid, GN_THREADS, lds, st>>>((const TT*)x, (const TT*)x2, C1, (double*)ws, HW, C, tpp, ppb);  \
   }
+#define GN_STATS_T(TT) switch (nchunk) { case 1: GN_STATS(TT, 1) break; case 2: GN_STATS(TT, 2) break; case 3: GN_STATS(TT, 3) break; default: GN_STATS(TT, 4) }
+  if (dtype == SDAMD_BF16) GN_STATS_T(bf16_t) else GN_STATS_T(float)
+#undef GN_STATS_T
+#undef GN_STATS
   SD_LAUNCH_CHECK("gn_stats");
   // apply: ~4K vectors (64 KB) per block, but keep >= ~1024 blocks in flight
   int vpp = C / V;
