@@ -266,11 +266,22 @@ __global__ __launch_bounds__(256) void conv3x3_cin_small_kernel(const float* __r
 // 3x3, pad 1, stride 1, tiny Cout (3, 4, 8): input NHWC T, output NCHW f32.
 // Weights [tap][Cin/V][COUT][V] in T.  8 lanes share one output pixel (each takes every 8th
 // 16-byte channel chunk: 128 contiguous bytes per pixel per instruction), then a shuffle reduce.
+// The whole filter (9*Cin*COUT elements, 46 KB for the UNet's f32 320->4 output conv) is staged in LDS once per
+// block: COUT weight vectors per input vector straight from global memory made the kernel L1-bandwidth-bound
+// (224 us for 16 x 64x64 pixels).
 template <typename T, int COUT>
-__global__ __launch_bounds__(256) void conv3x3_cout_small_kernel(const T* __restrict__ x, const T* __restrict__ w,
+__global__ __launch_bounds__(256) void conv3x3_cout_small_kernel(const T* __restrict__ x, const T* __restrict__ wg,
                                                                  const float* __restrict__ bias, float* __restrict__ y,
                                                                  int B, int H, int Wd, int Cin) {
   constexpr int V = 16 / sizeof(T);
+  extern __shared__ __attribute__((aligned(16))) char cs_smem[];
+  T* w = reinterpret_cast<T*>(cs_smem);
+  {
+    const int nv = 9 * Cin * COUT / V;
+    for (int i = threadIdx.x; i < nv; i += 256)
+      reinterpret_cast<u32x4_t*>(w)[i] = reinterpret_cast<const u32x4_t*>(wg)[i];
+  }
+  __syncthreads();
   const int sub = threadIdx.x & 7;
   const int cvs = Cin / V;
   const size_t npix = (size_t)B * H * Wd;
@@ -534,8 +545,14 @@ extern "C" int sdamd_conv3x3_cout_small(const void* x_nhwc, const void* w_packed
   hipStream_t st = (hipStream_t)stream;
   size_t npix = (size_t)B * H * Wd;
   size_t blocks = (npix * 8 + 255) / 256;
-  int g = (int)(blocks > 16384 ? 16384 : blocks);
-#define CS(TT, CO) conv3x3_cout_small_kernel<TT, CO><<<g, 256, 0, st>>>((const TT*)x_nhwc, (const TT*)w_packed, bias, y_nchw, B, H, Wd, Cin)
+  int g = (int)(blocks > 2048 ? 2048 : blocks);   // every block stages the filter once, then strides over pixels
+  const size_t lds = (size_t)9 * Cin * Cout * (dtype == SDAMD_BF16 ? 2 : 4);
+  SD_CHECK(lds <= 160 * 1024, "conv3x3_cout_small: filter of %zu bytes does not fit the LDS", lds);
+#define CS(TT, CO)                                                                                                     \
+  do {                                                                                                                 \
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)conv3x3_cout_small_kernel<TT, CO>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    conv3x3_cout_small_kernel<TT, CO><<<g, 256, lds, st>>>((const TT*)x_nhwc, (const TT*)w_packed, bias, y_nchw, B, H, Wd, Cin); \
+  } while (0)
   if (dtype == SDAMD_BF16) { if (Cout == 3) CS(bf16_t, 3); else if (Cout == 4) CS(bf16_t, 4); else CS(bf16_t, 8); }
   else { if (Cout == 3) CS(float, 3); else if (Cout == 4) CS(float, 4); else CS(float, 8); }
 #undef CS
