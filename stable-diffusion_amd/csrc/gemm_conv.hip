@@ -257,9 +257,8 @@ __global__ __launch_bounds__(256) void conv3x3_cin_small_kernel(const float* __r
         }
       }
     }
-    T* dst = y + pix * Cout + cq * 4;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) Cvt<T>::st(dst + r, acc[r]);
+    float o[4] = {acc[0], acc[1], acc[2], acc[3]};
+    store_n<T, 4>(y + pix * Cout + cq * 4, o);   // one 16-byte (f32) / 8-byte (bf16) store
   }
 }
 
