@@ -234,7 +234,12 @@ def main():
         roof, rows = roofline_leg(models, args, device)
         result["roofline"] = roof
         extra["kernel_breakdown"] = rows[:12]
-    if world == 1 and not args.skip_fp32_latency:   # BASELINE config 2: UNET step, UNet batch 2, fp32
+        # north_star: achieved HBM GB/s of the fused norm and sampler kernels against the 8 TB/s peak
+        extra["hbm_kernels"] = [r for r in rows if r["bound"] == "hbm"]
+    if world == 1 and not args.skip_fp32_latency:   # BASELINE config 2: UNET step, UNet batch 2, fp32 (and the same in bf16 mode)
+        j1 = Txt2ImgJob(models, 0, 1, args.denoise_steps, 7.5, device)
+        extra["unet_step_ms_bf16_b2"] = round(unet_step_ms(j1.loop, j1.latents0), 3)
+        del j1
         engine.set_compute_dtype(models["diffusion"], torch.float32)
         j2 = Txt2ImgJob(models, 0, 1, args.denoise_steps, 7.5, device)
         extra["unet_step_ms_fp32_b2"] = round(unet_step_ms(j2.loop, j2.latents0), 3)

@@ -136,8 +136,10 @@ def cfg_ddpm_step(latents, eps, noise, coef, step, cfg_scale, do_cfg=True, step_
         assert step_ptr.dtype == torch.int32 and step_ptr.is_cuda
     else:
         assert 0 <= step < coef.shape[0]
-    _lib.check(_lib.lib().sdamd_cfg_ddpm_step(_p(latents), _p(eps), _p(noise), _p(coef), _p(step_ptr), int(step),
-                                              float(cfg_scale), int(do_cfg), B, n, _stream()))
+    # algorithmic bytes: 5 x 4*h*w x 4 B per image-step (eps pos/neg, noise, latents in + out)
+    _timed("cfg_ddpm_step", 5.0 * B * n * 4,
+           lambda: _lib.check(_lib.lib().sdamd_cfg_ddpm_step(_p(latents), _p(eps), _p(noise), _p(coef), _p(step_ptr), int(step),
+                                                             float(cfg_scale), int(do_cfg), B, n, _stream())), f"B{B} n{n}")
     return latents
 
 
