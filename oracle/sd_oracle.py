@@ -344,7 +344,7 @@ def rescale(x, old, new, clamp=False):
 
 
 def generate(models, pos_ids, neg_ids, seed, steps=50, cfg_scale=7.5, input_image=None,
-             strength_start=None, preview_every_step=False, latent_hw=(64, 64), trace=None, sampler="ddpm"):
+             strength_start=None, preview_every_step=False, latent_hw=(64, 64), trace=None, sampler="ddpm", do_cfg=True):
     """txt2img / img2img restatement of pipeline.generate (pipeline.py:15-171), batch 1.
 
     models: dict of state_dicts {"clip","diffusion","decoder","encoder"}.  Token ids go in
@@ -355,8 +355,11 @@ def generate(models, pos_ids, neg_ids, seed, steps=50, cfg_scale=7.5, input_imag
     ``trace``: optional list that receives each step's latents.
     """
     g = torch.Generator().manual_seed(seed)
-    ctx = torch.cat([clip_forward(models["clip"], torch.tensor([pos_ids])),
-                     clip_forward(models["clip"], torch.tensor([neg_ids]))])        # :64 [pos; neg]
+    if do_cfg:
+        ctx = torch.cat([clip_forward(models["clip"], torch.tensor([pos_ids])),
+                         clip_forward(models["clip"], torch.tensor([neg_ids]))])    # :64 [pos; neg]
+    else:
+        ctx = clip_forward(models["clip"], torch.tensor([pos_ids]))                 # :66-70
     sampler = SAMPLERS[sampler](g)
     sampler.set_steps(steps)
     shape = (1, 4, latent_hw[0], latent_hw[1])
@@ -372,8 +375,11 @@ def generate(models, pos_ids, neg_ids, seed, steps=50, cfg_scale=7.5, input_imag
     image = None
     for t in sampler.timesteps:
         temb = get_time_embedding(t)
-        out = diffusion_forward(models["diffusion"], latents.repeat(2, 1, 1, 1), ctx, temb)
-        eps = cfg_scale * (out[0:1] - out[1:2]) + out[1:2]                          # :149
+        if do_cfg:
+            out = diffusion_forward(models["diffusion"], latents.repeat(2, 1, 1, 1), ctx, temb)
+            eps = cfg_scale * (out[0:1] - out[1:2]) + out[1:2]                      # :149
+        else:
+            eps = diffusion_forward(models["diffusion"], latents, ctx, temb)        # :151
         latents = sampler.step(t, latents, eps[0])                                  # noise shape (4,h,w)
         if trace is not None:
             trace.append(latents.clone())

@@ -205,6 +205,16 @@ def test_generate_txt2img_ddim_3step_vs_reference(models, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+def test_generate_without_cfg_vs_reference(models, dtype):
+    """do_cfg=False (pipeline.py:66-70,150-151): UNet batch 1, context = the prompt alone, no guidance combine."""
+    g = golden("pipeline_txt2img_nocfg_2step")
+    img, lat, final = _gen(models, dtype, steps=2, do_cfg=False)
+    errs = [rel_l2(lat[i], g["latents"][i]) for i in range(2)]
+    assert max(errs) < TOL[dtype], errs
+    _check_final_image(models, img, final, g, dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_denoise_steps_teacher_forced(models, dtype):
     """Each step fed the REFERENCE's previous latents (and the host noise stream): one UNet forward +
     CFG + DDPM step per comparison, no error carried between steps."""

@@ -197,3 +197,16 @@ def test_pipeline_txt2img_ddim_3step(model_sds, diffusion_sd):
         assert rel_l2(trace[i], g["latents"][i]) < TOL_MODEL, i
     diff = np.abs(img.astype(np.int32) - g["image"].astype(np.int32))
     assert diff.max() <= 1 and (diff > 0).mean() < 0.01
+
+
+@pytest.mark.slow
+def test_pipeline_txt2img_without_cfg(model_sds, diffusion_sd):
+    """do_cfg=False (pipeline.py:66-70,150-151): context is the prompt alone, no guidance combine."""
+    g = golden("pipeline_txt2img_nocfg_2step")
+    models = dict(model_sds, diffusion=diffusion_sd)
+    trace = []
+    img = O.generate(models, synth.synthetic_token_ids(0), synth.EMPTY_PROMPT_IDS, seed=42, steps=2, trace=trace, do_cfg=False)
+    for i in range(2):
+        assert rel_l2(trace[i], g["latents"][i]) < TOL_MODEL, i
+    diff = np.abs(img.astype(np.int32) - g["image"].astype(np.int32))
+    assert diff.max() <= 1 and (diff > 0).mean() < 0.01
