@@ -117,7 +117,11 @@ int sdamd_vae_sample(const float* x, const float* noise, float* out, const float
 /* ---- MFMA GEMM: nn.Linear / conv1x1 (attention.py:19-20,81-85; diffusion.py:18,54,82-85,
  * 156-157; clip.py:45-46).  C[m][n] = act(sum_k A[m][k]*W[n][k] + bias[n] + residual[m][n]);
  * K % 64 == 0, N % 16 == 0; `batch` independent problems with element strides.  C and the
- * residual share one type: f32 when out_f32 (or dtype f32), else bf16.  `ws` (may be null) is
+ * residual share one type: f32 when out_f32 (or dtype f32), else bf16.  out_f32 == 2 (bf16
+ * operands, act none, a shape with sdamd_gemm_tile != 0): f32 residual, and C is bf16 [M][2N]
+ * (ldc >= 2N) = [bf16(v) | bf16(v - bf16(v))], the two-term form sdamd_split_hilo makes -- used
+ * where the result is only ever read as the hi|lo operand of the next GEMM (linear_geglu_2 ->
+ * conv_output, diffusion.py:132-140).  `ws` (may be null) is
  * caller-owned scratch of ws_bytes for split-K partial sums: small-M / large-K problems then
  * spread K over more workgroups and a reduce kernel applies bias/residual/act. */
 int sdamd_gemm(const void* A, const void* W, void* C, const float* bias, const void* residual, int M,

@@ -396,7 +396,16 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm2_kernel(const GemmArgs p) 
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = silu_f(v[r]);
           }
-          *reinterpret_cast<f32x4_t*>(C + out_row(m) * p.ldc + n) = v;
+          if (p.out_f32 == 2) {   // hi|lo: [bf16(v) | bf16(v - bf16(v))] at columns n and N + n of a bf16 [M][2N] matrix
+            bf16_t* Ch = (bf16_t*)p.C + (size_t)batch * p.sC + out_row(m) * p.ldc + n;
+            float hi[4], lo[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { hi[r] = bf2f(f2bf(v[r])); lo[r] = v[r] - hi[r]; }
+            store_n<bf16_t, 4>(Ch, hi);
+            store_n<bf16_t, 4>(Ch + p.N, lo);
+          } else {
+            *reinterpret_cast<f32x4_t*>(C + out_row(m) * p.ldc + n) = v;
+          }
         }
       }
       __builtin_amdgcn_wave_barrier();
@@ -475,7 +484,14 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[r] = silu_f(v[r]);
     }
-    if (p.out_f32) {
+    if (p.out_f32 == 2) {
+      bf16_t* Ch = (bf16_t*)p.C + m * p.ldc + n;
+      float hi[4], lo[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { hi[r] = bf2f(f2bf(v[r])); lo[r] = v[r] - hi[r]; }
+      store_n<bf16_t, 4>(Ch, hi);
+      store_n<bf16_t, 4>(Ch + p.N, lo);
+    } else if (p.out_f32) {
       *reinterpret_cast<f32x4_t*>((float*)p.C + m * p.ldc + n) = v;
     } else {
       const u32x2_t o = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
@@ -575,6 +591,7 @@ int gemm2_choose_tile(int M, int N, int K, int batch, int mode, size_t ws_bytes,
 template <typename T>
 static int launch_gemm2_t(GemmArgs& a, int batch, bool conv, int mode, hipStream_t st) {
   if (conv && a.ups) return -1;   // gathered nearest-2x conv: gemm_conv.hip (the models use the phase form)
+  if (a.out_f32 == 2 && (sizeof(T) != 2 || conv || a.act != ACT_NONE || a.ldc % 4 != 0)) return -1;   // hi|lo output: bf16 dense GEMM only
   if ((a.ldr % 4) != 0 || (a.R && ((uintptr_t)a.R % 16) != 0)) return -1;
   if (sizeof(T) == 2 && !a.out_f32 && ((a.ldc % 8) != 0 || (a.sC % 8) != 0)) return -1;   // 16-byte row-segment stores
   if (sizeof(T) == 4 && ((a.ldc % 4) != 0 || (a.sC % 4) != 0)) return -1;

@@ -455,7 +455,8 @@ extern "C" int sdamd_gemm(const void* A, const void* W, void* C, const float* bi
   a.act = act; a.out_f32 = out_f32;
   if (int e = check_common(a, dtype, "gemm")) return e;
   const int esz = dtype == SDAMD_BF16 ? 2 : 4;
-  SD_CHECK((lda * esz) % 16 == 0 && lda >= K && ldw >= K && ldc >= (act == ACT_GEGLU ? N / 2 : N), "gemm: bad leading dimensions lda=%d ldw=%d ldc=%d", lda, ldw, ldc);
+  SD_CHECK((lda * esz) % 16 == 0 && lda >= K && ldw >= K && ldc >= (act == ACT_GEGLU ? N / 2 : out_f32 == 2 ? 2 * N : N), "gemm: bad leading dimensions lda=%d ldw=%d ldc=%d", lda, ldw, ldc);
+  SD_CHECK(out_f32 >= 0 && out_f32 <= 2, "gemm: out_f32=%d (0 operand type, 1 f32, 2 bf16 hi|lo)", out_f32);
   SD_CHECK(batch >= 1, "gemm: batch=%d", batch);
   SD_CHECK(!residual || (ldr >= N && ldr % 4 == 0 && ((uintptr_t)residual % 16) == 0), "gemm: residual needs ldr=%d >= N, ldr %% 4 == 0 and 16-byte alignment", ldr);
   hipStream_t st = (hipStream_t)stream;
@@ -464,6 +465,7 @@ extern "C" int sdamd_gemm(const void* A, const void* W, void* C, const float* bi
     if (r >= 0) return r;
   }
   SD_CHECK(act != ACT_GEGLU, "gemm: the fused GeGLU epilogue needs bf16, N %% 256 == 0, no residual, bf16 output and the 8-wave kernels");
+  SD_CHECK(out_f32 != 2, "gemm: the hi|lo output needs bf16 operands and a shape the LDS-DMA kernels take (sdamd_gemm_tile != 0)");
   if (dtype == SDAMD_BF16) return pick_tile<bf16_t, false>(a, batch, st);
   return pick_tile<float, false>(a, batch, st);
 }

@@ -97,6 +97,9 @@ class UNET_AttentionBlock(engine.HipModule):
         t = engine.self_attention(engine.layernorm(t, self.layernorm_1, dt), self.attention_1, residual=t)
         t = engine.cross_attention(engine.layernorm(t, self.layernorm_2, dt), self.attention_2, kv, residual=t)
         g = engine.linear_geglu(engine.layernorm(t, self.layernorm_3, dt), self.linear_geglu_1)
+        ts = engine.linear_hilo(g, self.linear_geglu_2, t) if dt == torch.bfloat16 else None
+        if ts is not None:   # t is only ever read as conv_output's hi|lo operand: the GEMM epilogue writes that form
+            return engine.conv1x1_presplit(ts.view(B, H, W, 2 * C), self.conv_output, x)
         t = engine.linear(g, self.linear_geglu_2, residual=t)
         return engine.conv1x1(t.view(B, H, W, C), self.conv_output, residual=x, compute_dtype=dt)
 

@@ -128,6 +128,23 @@ def linear_geglu(x, lin):
     return ops.geglu(linear(x, lin))
 
 
+def linear_hilo(x, lin, residual):
+    """linear(x) + residual (f32) emitted directly as the bf16 hi|lo pair [.., 2N] that conv1x1_presplit takes, or
+    None when this problem does not run on the kernels that can (the caller then uses linear + conv1x1)."""
+    M = x.numel() // x.shape[-1]
+    if x.dtype != torch.bfloat16 or residual is None or residual.dtype != torch.float32 or \
+            not ops.gemm_hilo_fused(M, lin.out_features, lin.in_features, x.dtype):
+        return None
+    return ops.gemm(x, linear_w(lin, x.dtype), bias_of(lin), residual, ops.ACT_NONE, out_hilo=True)
+
+
+def conv1x1_presplit(xs, conv, residual):
+    """conv1x1 of an operand that already is the hi|lo pair [..., 2C] (see conv1x1): f32 residual, f32 result."""
+    w2 = packed(conv.weight, "c1x2", torch.bfloat16,
+                lambda w: w.reshape(w.shape[0], w.shape[1]).to(torch.bfloat16).repeat(1, 2).contiguous())
+    return ops.gemm(xs, w2, bias_of(conv), residual, ops.ACT_NONE, True)
+
+
 def conv1x1(x, conv, residual=None, out_dtype=None, compute_dtype=None, x2=None):
     """x NHWC [B,H,W,C].  An f32 ``x`` under a bf16 compute dtype is the residual trunk itself:
     it goes through the MFMA as two bf16 terms (hi|lo) against [W|W] instead of being rounded.

@@ -8,6 +8,8 @@ Activation layout is NHWC / token-major: [B, H, W, C] or [B, S, C], float32 or b
 """
 import math
 
+import os
+
 import torch
 
 from . import _lib
@@ -378,9 +380,20 @@ def vae_sample(moments, noise, w, b):
 
 
 # ------------------------------------------------------------------ MFMA GEMM / conv / attention
-def gemm(a, w, bias=None, residual=None, act=ACT_NONE, out_f32=False):
+def gemm_hilo_fused(M, N, K, dtype):
+    """True when sdamd_gemm can emit its result directly as the bf16 hi|lo pair (out_f32 = 2)."""
+    if dtype != torch.bfloat16 or not gemm_supports_act(ACT_GEGLU, dtype, 256):    # 4-wave kernels forced
+        return False
+    if os.environ.get("SDAMD_NO_HILO_FUSE"):     # experiments/ab_bench.sh: A/B against a library without it
+        return False
+    tile = _lib.lib().sdamd_gemm_tile(M, N, K, 1, _code(dtype), GEMM_WS_BYTES, 0) % 1000000
+    return tile in (128160, 128320, 256256)      # the LDS-DMA tiles (gemm2.hip); the 4-wave ones have no such epilogue
+
+
+def gemm(a, w, bias=None, residual=None, act=ACT_NONE, out_f32=False, out_hilo=False):
     """a [..., K] (last dim contiguous, uniform row stride), w [N, K] -> [..., N].  The result (and the
-    residual, which must have the result's dtype) is f32 when ``out_f32``, else a's dtype."""
+    residual, which must have the result's dtype) is f32 when ``out_f32``, else a's dtype.
+    ``out_hilo``: f32 residual, result bf16 [..., 2N] = [bf16(v) | bf16(v - bf16(v))] (see split_hilo)."""
     _dev(a, w, bias, residual)
     K = a.shape[-1]
     N = w.shape[0]
@@ -397,11 +410,15 @@ def gemm(a, w, bias=None, residual=None, act=ACT_NONE, out_f32=False):
         lda = K
     out_dtype = torch.float32 if out_f32 else a.dtype
     n_out = N // 2 if act == ACT_GEGLU else N     # GEGLU: w rows are value|gate tiles, see geglu_pack
+    res_dtype = out_dtype
+    if out_hilo:
+        assert a.dtype == torch.bfloat16 and act == ACT_NONE and not out_f32
+        res_dtype, n_out, out_f32 = torch.float32, 2 * N, 2
     out = torch.empty(lead + (n_out,), dtype=out_dtype, device=a.device)
     ldr = 0
     if residual is not None:
-        assert residual.dtype == out_dtype and residual.is_contiguous() and residual.numel() == M * n_out, \
-            (residual.dtype, out_dtype, residual.shape, M, N)
+        assert residual.dtype == res_dtype and residual.is_contiguous() and residual.numel() == M * (N if out_hilo else n_out), \
+            (residual.dtype, res_dtype, residual.shape, M, N)
         ldr = N
     if bias is not None:
         assert bias.dtype == torch.float32 and bias.numel() == N and bias.is_contiguous()
@@ -410,7 +427,7 @@ def gemm(a, w, bias=None, residual=None, act=ACT_NONE, out_f32=False):
            lambda: _lib.check(_lib.lib().sdamd_gemm(_p(a), _p(w), _p(out), _p(bias), _p(residual), M, N, K, lda, K, n_out, ldr, 1,
                                                     0, 0, 0, 0, int(act), _code(a.dtype), int(out_f32), _p(ws), ws.numel(),
                                                     _stream())),
-           f"M{M} N{N} K{K}{' +res' if residual is not None else ''}{' f32out' if out_f32 else ''}{' geglu' if act == ACT_GEGLU else ''}")
+           f"M{M} N{N} K{K}{' +res' if residual is not None else ''}{' hilo' if out_f32 == 2 else ' f32out' if out_f32 else ''}{' geglu' if act == ACT_GEGLU else ''}")
     return out
 
 

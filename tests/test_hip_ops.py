@@ -142,6 +142,24 @@ def test_groupnorm_and_split_hilo_over_a_virtual_concat(C1, C2, HW):
     assert torch.equal(ops.split_hilo(a, b), ops.split_hilo(full))
 
 
+@pytest.mark.parametrize("impl", [0, 3], ids=["auto", "splitk3"])
+@pytest.mark.parametrize("M,N,K", [(4096, 320, 1280), (512, 640, 2560), (256, 1280, 5120), (1000, 320, 640)])
+def test_gemm_hilo_output_equals_split_of_f32_output(M, N, K, impl, request):
+    """out_f32 = 2: the epilogue writes [bf16(v) | bf16(v - bf16(v))] -- bit-equal to split_hilo of the f32 result
+    (same accumulators, same residual add), with and without split-K."""
+    from sd_amd import _lib
+    old = _lib.lib().sdamd_set_gemm_impl(impl)
+    request.addfinalizer(lambda: _lib.lib().sdamd_set_gemm_impl(old))
+    a, w = rnd("hl.a", (M, K)).bfloat16().to(DEV), (rnd("hl.w", (N, K)) * K ** -0.5).bfloat16().to(DEV)
+    b, r = rnd("hl.b", (N,)).to(DEV), rnd("hl.r", (M, N), 3.0).to(DEV)
+    if not ops.gemm_hilo_fused(M, N, K, torch.bfloat16):
+        pytest.skip("this shape / kernel family has no hi|lo epilogue")
+    want = ops.split_hilo(ops.gemm(a, w, b, r, out_f32=True))
+    got = ops.gemm(a, w, b, r, out_hilo=True)
+    assert got.dtype == torch.bfloat16 and tuple(got.shape) == (M, 2 * N)
+    assert torch.equal(got, want)
+
+
 def test_gather_row_and_silu():
     table = rnd("gather", (5, 96))
     dst = torch.empty(96, device=DEV)
