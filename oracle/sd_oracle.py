@@ -327,7 +327,49 @@ class DDIMSampler:
     add_noise = DDPMSampler.add_noise                                               # :74-93, same math
 
 
-SAMPLERS = {"ddpm": DDPMSampler, "ddim": DDIMSampler}
+class EulerSampler(DDPMSampler):
+    """sampler/euler.py:4-100.  ``corrected=False``: the class as written -- ascending timesteps (:26-29) and the
+    step of :54-77, finite only where the previous timestep is >= 0.  ``corrected=True``: descending timesteps and
+    one explicit Euler step of the probability-flow ODE in sigma space per interval (no reference counterpart:
+    parity unpinned; stated here in its sigma form, which the product's closed form has to reproduce)."""
+
+    def __init__(self, generator, training_steps=1000, beta_start=0.00085, beta_end=0.0120, corrected=False):
+        super().__init__(generator, training_steps, beta_start, beta_end)
+        self.corrected = corrected
+
+    def set_steps(self, steps):                                                     # :23-29 (no [::-1])
+        self.steps = steps
+        ts = (np.arange(0, steps) * (self.training_steps // steps)).astype(np.int64)
+        self.timesteps = torch.from_numpy(ts[::-1].copy() if self.corrected else ts)
+
+    def step(self, t, latents, model_output, noise=None):
+        f = np.float32
+        t = int(t)
+        pt = self._prev(t)
+        a_t = f(self.alpha_cumprod[t].item())
+        a_p = f(self.alpha_cumprod[pt].item()) if pt >= 0 else f(1.0)
+        if self.corrected:
+            a_t, a_p = float(a_t), float(a_p)                                       # float64 closed form
+            sig_t, sig_p = np.sqrt((1 - a_t) / a_t), np.sqrt((1 - a_p) / a_p)
+            xs = latents.double() / np.sqrt(a_t)                                    # sample in sigma space
+            xs = xs + (sig_p - sig_t) * model_output.double()                       # dx/dsigma = eps
+            return (xs * np.sqrt(a_p)).float()
+        with np.errstate(divide="ignore", invalid="ignore"):
+            sa, sb = np.sqrt(a_t), np.sqrt(f(1) - a_t)
+            c0 = (np.sqrt(a_p) * (f(1) - a_t)) / (f(1) - a_p)                       # :63
+            cx = sb * (f(1) - a_t) / (f(1) - a_p)                                   # :64
+            var = np.maximum((f(1) - a_p) / (f(1) - a_t) * (f(1) - a_t / a_p), f(1e-20))   # :36-47
+        sa, sb, c0, cx, sigma = (torch.tensor(v, dtype=torch.float32) for v in (sa, sb, c0, cx, np.sqrt(var)))
+        x0 = (latents - sb * model_output) / sa                                     # :61
+        prev = c0 * x0 + cx * latents                                               # :66
+        if t > 0:                                                                   # :70-73
+            if noise is None:
+                noise = torch.randn(model_output.shape, generator=self.generator, dtype=model_output.dtype)
+            prev = prev + sigma * noise
+        return prev
+
+
+SAMPLERS = {"ddpm": DDPMSampler, "ddim": DDIMSampler, "euler": lambda g: EulerSampler(g, corrected=True)}
 
 
 def get_time_embedding(t):

@@ -18,6 +18,13 @@ import torch
 from . import engine, ops
 from .sampler.ddim import DDIMSampler  # noqa: F401  (resolved by name, see _resolve_sampler)
 from .sampler.ddpm import DDPMSampler  # noqa: F401
+from .sampler.euler import EulerSampler as _EulerSampler
+
+
+def EulerSampler(generator):
+    """What ``sampler="euler"`` resolves to: the corrected Euler sampler -- the literal reference class has no finite
+    run to offer (sampler/euler.py; both modes are described there)."""
+    return _EulerSampler(generator, corrected=True)
 
 WIDTH = 512
 HEIGHT = 512
@@ -188,7 +195,7 @@ def prepare_latents(seeds, sampler_cls, steps, shape, device, encoder=None, imag
     timesteps = samplers[0].timesteps
     coef = samplers[0].coefficient_table(timesteps)
     noise = None
-    if sampler_cls.stochastic:
+    if samplers[0].stochastic:
         noise = torch.zeros((len(timesteps), len(seeds)) + tuple(shape[1:]), dtype=torch.float32)
         for si, t in enumerate(timesteps):
             if int(t) > 0:

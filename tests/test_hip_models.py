@@ -204,6 +204,21 @@ def test_generate_txt2img_ddim_3step_vs_reference(models, dtype):
     _check_final_image(models, img, final, g, dtype)
 
 
+def test_generate_euler_vs_oracle(models):
+    """sampler="euler"  builds the corrected Euler sampler: deterministic, descending schedule.
+    **Parity unpinned** -- the reference's class has no finite run (sampler/euler.py, see sd_amd/sampler/euler.py);
+    checked against the CPU oracle's sigma-space Euler loop over the oracle's own UNet, f32, 2 steps."""
+    img, lat, final = _gen(models, FP32, sampler="euler", steps=2)
+    sds = {name: {k: v.cpu() for k, v in m.state_dict().items()} for name, m in models.items()}
+    trace = []
+    want = O.generate(sds, synth.synthetic_token_ids(0), synth.EMPTY_PROMPT_IDS, seed=42, steps=2, cfg_scale=7.5,
+                      trace=trace, sampler="euler")
+    errs = [rel_l2(lat[i], trace[i]) for i in range(2)]
+    assert torch.isfinite(final).all() and max(errs) < TOL[FP32], errs
+    diff = np.abs(img.astype(np.int32) - want.astype(np.int32))
+    assert diff.max() <= 1 and (diff > 0).mean() < 0.01
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_generate_without_cfg_vs_reference(models, dtype):
     """do_cfg=False (pipeline.py:66-70,150-151): UNet batch 1, context = the prompt alone, no guidance combine."""
@@ -294,8 +309,8 @@ def test_generate_errors_match_reference(models):
     kw = dict(models=models, device="cuda", tokenizer=synth.SyntheticTokenizer())
     with pytest.raises(ValueError, match="Strength must be between 0 and 1"):
         pipeline.generate("synthetic:0", "", strength=0.0, **kw)
-    with pytest.raises(ValueError, match="Sampler 'euler' not found"):     # pipeline.py:84 (euler.py is never imported)
-        pipeline.generate("synthetic:0", "", sampler="euler", steps=2, **kw)
+    with pytest.raises(ValueError, match="Sampler 'heun' not found"):      # pipeline.py:84
+        pipeline.generate("synthetic:0", "", sampler="heun", steps=2, **kw)
     with pytest.raises(Exception, match="HIP device"):
         pipeline.generate("synthetic:0", "", models=models, device="cpu", tokenizer=synth.SyntheticTokenizer())
 

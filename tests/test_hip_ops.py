@@ -15,7 +15,7 @@ import sd_amd
 from sd_amd import ops, synth
 from sd_amd.sampler.ddpm import DDPMSampler
 from oracle import sd_oracle as O
-from conftest import rel_l2, hin
+from conftest import golden, rel_l2, hin
 
 pytestmark = pytest.mark.gpu
 torch.set_grad_enabled(False)
@@ -96,6 +96,24 @@ def test_sampler_step_and_add_noise_match_golden():
     out = ops.add_noise(x, torch.from_numpy(g["add_noise_780_noise"]).to(DEV), float(np.sqrt(a)), float(np.sqrt(np.float32(1) - a)))
     assert np.array_equal(out.cpu().numpy(), g["add_noise_780"])
     assert rel_l2(sm.add_noise(x, torch.tensor(780)).cpu(), g["add_noise_780"]) < 1e-6
+
+
+def test_euler_step_matches_golden():
+    """sampler/euler.py:54-77 through the fused step kernel: the literal step vs the reference class where it is
+    finite; the corrected mode vs the oracle's sigma-space Euler step."""
+    from sd_amd.sampler.euler import EulerSampler
+    g = golden("euler_step")
+    for steps, ts in ((50, (980, 500, 20)), (20, (950, 50))):
+        for t in ts:
+            lat, eps = hin(f"euler.lat.{t}", (1, 4, 16, 16), 2.0), hin(f"euler.eps.{t}", (1, 4, 16, 16), 1.5)
+            sm = EulerSampler(torch.Generator().manual_seed(4321 + t)); sm.set_steps(steps)
+            got = sm.step(t, lat.to(DEV), eps.to(DEV)).cpu()
+            assert rel_l2(got, g[f"step{steps}_{t}"]) < 1e-6, (steps, t)
+    om = O.EulerSampler(torch.Generator().manual_seed(0), corrected=True); om.set_steps(50)
+    pm = EulerSampler(torch.Generator().manual_seed(0), corrected=True); pm.set_steps(50)
+    for t in (980, 500, 20, 0):
+        lat, eps = hin(f"euler.lat.{t}", (1, 4, 16, 16), 2.0), hin(f"euler.eps.{t}", (1, 4, 16, 16), 1.5)
+        assert rel_l2(pm.step(t, lat.to(DEV), eps.to(DEV)).cpu(), om.step(t, lat, eps)) < 1e-6, t
 
 
 def test_ddim_step_matches_golden():

@@ -80,6 +80,57 @@ def test_ddim_tables_and_step_bit_exact():
     assert np.array_equal(sm.add_noise(x, torch.tensor(780), noise=torch.from_numpy(g["add_noise_780_noise"])).numpy(), g["add_noise_780"])
 
 
+def test_euler_tables_and_step_bit_exact():
+    """Oracle EulerSampler and the product's host-side schedule / coefficient rows vs the reference class
+    (sampler/euler.py) wherever its step is finite; its t = 0 step (the first of its ascending schedule) is not."""
+    from sd_amd.sampler.euler import EulerSampler as ProductEuler
+    g = golden("euler_step")
+    assert float(g["step50_0_finite_fraction"]) == 0.0
+    for cls in (O.EulerSampler, ProductEuler):
+        s = cls(torch.Generator().manual_seed(0))
+        assert np.array_equal(s.alpha_cumprod.numpy(), g["alpha_cumprod"]) and np.array_equal(s.betas.numpy(), g["betas"])
+        assert np.array_equal(s.timesteps.numpy(), g["timesteps_default"])
+        s.set_steps(50)
+        assert np.array_equal(s.timesteps.numpy(), g["timesteps50"]) and s.timesteps[0] == 0    # ascending (literal)
+        s.set_steps(20)
+        assert np.array_equal(s.timesteps.numpy(), g["timesteps20"])
+        c = cls(torch.Generator().manual_seed(0), corrected=True); c.set_steps(50)
+        assert np.array_equal(c.timesteps.numpy(), g["timesteps50"][::-1])
+    for steps, ts in ((50, (980, 500, 20)), (20, (950, 50))):
+        for t in ts:
+            lat, eps = hin(f"euler.lat.{t}", (1, 4, 16, 16), 2.0), hin(f"euler.eps.{t}", (1, 4, 16, 16), 1.5)
+            noise = torch.from_numpy(g[f"noise{steps}_{t}"])
+            sm = O.EulerSampler(torch.Generator().manual_seed(4321 + t)); sm.set_steps(steps)
+            assert np.array_equal(sm.step(t, lat, eps, noise=noise).numpy(), g[f"step{steps}_{t}"]), (steps, t)
+            assert rel_l2(sm.step(t, lat, eps), g[f"step{steps}_{t}"]) < 1e-6         # same generator consumption
+            pm = ProductEuler(torch.Generator().manual_seed(1)); pm.set_steps(steps)
+            c = pm.step_coefficients(t).numpy()
+            want = ((lat - c[1] * eps) / c[0]) * c[2] + c[3] * lat + c[4] * noise
+            assert rel_l2(want, g[f"step{steps}_{t}"]) < 1e-6 and tuple(c[5:]) == (1, 0, 0)
+    pm = ProductEuler(torch.Generator().manual_seed(1)); pm.set_steps(50)
+    assert not np.isfinite(pm.step_coefficients(0).numpy()[2:4]).any()               # 1 - abar_prev = 0, as in the reference
+
+
+def test_euler_corrected_is_an_euler_step_in_sigma_space():
+    """corrected=True (parity unpinned: no reference counterpart): the product's closed-form row equals the oracle's
+    explicit Euler step of dx/dsigma = eps, ends on x0 at the last step, and a whole run stays finite."""
+    from sd_amd.sampler.euler import EulerSampler as ProductEuler
+    om = O.EulerSampler(torch.Generator().manual_seed(0), corrected=True); om.set_steps(50)
+    pm = ProductEuler(torch.Generator().manual_seed(0), corrected=True); pm.set_steps(50)
+    assert not pm.stochastic and pm.timesteps[0] == 980 and pm.timesteps[-1] == 0
+    for t in (980, 500, 20, 0):
+        lat, eps = hin(f"euler.lat.{t}", (1, 4, 16, 16), 2.0), hin(f"euler.eps.{t}", (1, 4, 16, 16), 1.5)
+        c = pm.step_coefficients(t).numpy()
+        got = ((lat - c[1] * eps) / c[0]) * c[2] + c[3] * eps
+        assert tuple(c[4:]) == (0, 0, 1, 0) and rel_l2(got, om.step(t, lat, eps)) < 1e-6, t
+        if t == 0:
+            assert rel_l2(got, (lat - c[1] * eps) / c[0]) < 1e-7                     # abar_prev = 1: lands on x0
+    x = hin("euler.run", (1, 4, 8, 8))
+    for t in om.timesteps:
+        x = om.step(t, x, 0.1 * x)
+    assert torch.isfinite(x).all()
+
+
 def _attn_shapes(dim, bias_in, cross=False):
     if cross:
         s = {"q_proj.weight": (dim, dim), "k_proj.weight": (dim, 768), "v_proj.weight": (dim, 768)}

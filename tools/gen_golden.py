@@ -6,7 +6,7 @@ imports the reference's modules unmodified, fills them with the hash weights of
 ``stable-diffusion_amd/synth.py`` (same state_dict keys), feeds hash/seeded inputs and
 stores the outputs.  Fixtures are data only -- no reference source is copied.
 
-    python tools/gen_golden.py [keys] [small] [models] [pipe3] [img2img] [pipe50] [converter] [ddim] [nocfg]
+    python tools/gen_golden.py [keys] [small] [models] [pipe3] [img2img] [pipe50] [converter] [ddim] [nocfg] [euler]
 """
 import contextlib
 import io
@@ -258,6 +258,29 @@ def gen_ddim():
          n_steps=np.int64(len(rec)))
 
 
+def gen_euler():
+    """The reference's EulerSampler class (sampler/euler.py): schedule tables and its step wherever that is finite
+    (previous timestep >= 0).  At t = 0 -- the first timestep of its ascending schedule -- it divides by zero."""
+    from sampler.euler import EulerSampler as RefEuler
+    s = RefEuler(torch.Generator().manual_seed(0))
+    out = dict(alpha_cumprod=s.alpha_cumprod, betas=s.betas, timesteps_default=s.timesteps.clone())
+    s.set_steps(50)
+    out["timesteps50"] = s.timesteps.clone()
+    s20 = RefEuler(torch.Generator().manual_seed(0)); s20.set_steps(20)
+    out["timesteps20"] = s20.timesteps
+    for steps, ts in ((50, (980, 500, 20)), (20, (950, 50))):
+        for t in ts:
+            sm = RefEuler(torch.Generator().manual_seed(4321 + t)); sm.set_steps(steps)
+            lat = hin(f"euler.lat.{t}", (1, 4, 16, 16), 2.0)
+            eps = hin(f"euler.eps.{t}", (1, 4, 16, 16), 1.5)
+            out[f"step{steps}_{t}"] = sm.step(t, lat, eps)
+            out[f"noise{steps}_{t}"] = torch.randn((1, 4, 16, 16), generator=torch.Generator().manual_seed(4321 + t))
+    sm = RefEuler(torch.Generator().manual_seed(5)); sm.set_steps(50)
+    first = sm.step(0, hin("euler.lat.0", (1, 4, 16, 16), 2.0), hin("euler.eps.0", (1, 4, 16, 16), 1.5))
+    out["step50_0_finite_fraction"] = np.float64(torch.isfinite(first).double().mean().item())
+    save("euler_step", **out)
+
+
 def gen_converter():
     """Run the reference's model_converter on a synthetic CompVis-layout checkpoint and record what
     it produced.  The checkpoint's key list is read out of the reference's text (the quoted
@@ -315,6 +338,8 @@ def main():
         gen_pipeline(5, "pipeline_img2img_5step_s0998", input_image=pil, strength=0.998)
     if "ddim" in what:
         gen_ddim()
+    if "euler" in what:
+        gen_euler()
     if "converter" in what:
         gen_converter()
     if "nocfg" in what:      # pipeline.py:66-70,136-137,150-151: no guidance, context = the prompt alone
