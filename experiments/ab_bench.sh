@@ -2,7 +2,7 @@
 # Same-box A/B of two builds of libsdamd.so on the headline bench: experiments/ab/libsdamd_old.so vs the in-tree one.
 set -e
 for i in 1 2; do
-  SDAMD_NO_HILO_FUSE=1 SDAMD_LIB=$PWD/experiments/ab/libsdamd_old.so timeout -k 10 300 python bench.py --steps 2 --warmup 1 --skip-cpu-baseline --skip-roofline --skip-fp32-latency > gpurun_out/ab_old_$i.json
+  SDAMD_LIB=$PWD/experiments/ab/libsdamd_old.so timeout -k 10 300 python bench.py --steps 2 --warmup 1 --skip-cpu-baseline --skip-roofline --skip-fp32-latency > gpurun_out/ab_old_$i.json
   timeout -k 10 300 python bench.py --steps 2 --warmup 1 --skip-cpu-baseline --skip-roofline --skip-fp32-latency > gpurun_out/ab_new_$i.json
 done
 python - <<'PY'

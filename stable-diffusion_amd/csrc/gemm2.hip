@@ -54,7 +54,12 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
 #define GEMM2_DBG(x) ((CONV || WGM * WGN == 4) && p.debug == (x))
 #endif
 
-template <typename T, int BM, int BN, int WGM, int WGN, int STAGES, bool CONV>
+// EPI 0: every epilogue (split-K partials, GeGLU, f32 / hi|lo, operand type), chosen at run time.
+// EPI 1: the f32 / hi|lo epilogue with an f32 residual only, the residual prefetched ahead of the K loop (a kernel
+// of its own: the other epilogues' code and the unrolled prefetch would otherwise sit in every launch's I-cache
+// footprint -- a first build with both in one kernel made the launches WITHOUT a residual 6-13 us slower in a
+// UNet step, where consecutive launches are different kernels, while a back-to-back microbenchmark saw nothing).
+template <typename T, int BM, int BN, int WGM, int WGN, int STAGES, bool CONV, int EPI>
 __global__ __launch_bounds__(WGM* WGN * 64) void gemm2_kernel(const GemmArgs p) {
   constexpr bool F32 = sizeof(T) == 4;     // exact-f32 MFMA (v_mfma_f32_16x16x4_f32) on f32 operands
   constexpr int EPC = 16 / sizeof(T);      // elements per 16-byte chunk
@@ -88,7 +93,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm2_kernel(const GemmArgs p) 
   // pixel (2y+py, 2x+px) of conv3x3(nearest2x(in)) only sees the 2x2 input window starting at
   // (y-(1-py), x-(1-px)), with the 3x3 taps that land on the same input pixel pre-summed on the host:
   // 4/9 of the MACs.  Rows m index the LOW-resolution grid; out_row() maps them to the output.
-  const bool phase_up = CONV && p.phase_up;
+  const bool phase_up = CONV && EPI == 0 && p.phase_up;   // (the phase form never carries a residual)
   const int py = phase_up ? (batch >> 1) : 0, px = phase_up ? (batch & 1) : 0;
   const int ntx = phase_up ? 2 : 3;                       // taps per filter row
   auto out_row = [&](int m) -> size_t {
@@ -279,6 +284,35 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm2_kernel(const GemmArgs p) 
   int kt = 0;
   stage_tile(smem, kt_begin * BKE);
   if (STAGES == 3 && nk > 1) stage_tile(smem + STAGE, (kt_begin + 1) * BKE);
+  // f32 residual prefetch: the epilogue's residual chunks (same (m, n) per lane as its row-segment stores) are
+  // requested here, behind the first K-tile's DMA, so the fetch overlaps the K loop instead of standing between
+  // the last MFMA and the first store -- the short-K GEMMs on the f32 trunk are bound by exactly those bytes.
+  // Only where the 80 extra registers fit beside two waves per SIMD (launch2 picks EPI accordingly).
+  constexpr bool RPRE = EPI == 1;
+  constexpr int E_CPR = WTN / 4;                          // 16-byte chunks per sub-tile row (f32 epilogue)
+  constexpr int E_RS = WTN * 4 + 16;
+  constexpr int E_IPMAX = (STAGES * STAGE / NW) / (16 * E_RS);
+  constexpr int E_IP = E_IPMAX >= TM ? TM : (E_IPMAX >= TM / 2 && TM % 2 == 0) ? TM / 2 : (E_IPMAX >= TM / 4 && TM % 4 == 0) ? TM / 4 : 1;
+  constexpr int E_IT = E_IP * 16 * E_CPR / 64;            // chunks per lane and pass
+  static_assert(!RPRE || (E_IP * 16 * E_CPR) % 64 == 0, "residual prefetch expects whole lane rounds");
+  f32x4_t rpre[RPRE ? (TM / E_IP) * E_IT : 1];
+  if constexpr (RPRE) {
+    // (the always-true run-time test keeps the block a region of its own: scheduled together with the prologue
+    // the 20 address computations stay live across it and the kernel spills)
+    if (p.R) {
+      const float* __restrict__ Rf = (const float*)p.R + (size_t)batch * p.sR;
+      const int mw = m0 + wm * WTM, nw = n0 + wn * WTN;
+#pragma unroll
+      for (int ps = 0; ps < TM / E_IP; ++ps)
+#pragma unroll
+        for (int it = 0; it < E_IT; ++it) {
+          const int idx = lane + it * 64;
+          const int row = idx / E_CPR, ch = idx - row * E_CPR;
+          const int m = mw + ps * E_IP * 16 + row, n = nw + ch * 4;
+          rpre[ps * E_IT + it] = (m < p.M && n < p.N) ? *reinterpret_cast<const f32x4_t*>(Rf + out_row(m) * p.ldr + n) : (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        }
+    }
+  }
   if (STAGES == 2) {
     for (;;) {
       GEMM2_STEP(0, 1)
@@ -293,7 +327,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm2_kernel(const GemmArgs p) 
   }
 #undef GEMM2_STEP
 
-  if (p.splits > 1) {  // raw f32 partial sums; bias / residual / activation happen in splitk_reduce_kernel
+  if (!RPRE && p.splits > 1) {  // raw f32 partial sums; bias / residual / activation happen in splitk_reduce_kernel
     float* __restrict__ ws = p.ws + (size_t)split * p.M * p.N;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -319,7 +353,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm2_kernel(const GemmArgs p) 
   __syncthreads();  // every wave is done reading the last K-tile (and no DMA is outstanding)
   const float* __restrict__ bias = p.bias;
   const int mw = m0 + wm * WTM, nw = n0 + wn * WTN;  // this wave's sub-tile origin
-  if (!F32 && p.act == ACT_GEGLU) {
+  if (!RPRE && !F32 && p.act == ACT_GEGLU) {
     // GeGLU epilogue (diffusion.py:128-130): the weight rows were packed so that 16-column tile 2c
     // holds the value channels [16c, 16c+16) and tile 2c+1 their gates; value * gelu_erf(gate) is
     // lane-local on the f32 accumulators and only the N/2 products are rounded and stored (bf16).
@@ -361,7 +395,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm2_kernel(const GemmArgs p) 
         __builtin_amdgcn_wave_barrier();
       }
     }
-  } else if (F32 || p.out_f32) {
+  } else if (RPRE || F32 || p.out_f32) {
     constexpr int RS = WTN * 4 + 16;                     // padded LDS row stride (bytes)
     constexpr int IPMAX = (STAGES * STAGE / NW) / (16 * RS);  // 16-row tiles per pass that fit the wave's slice
     constexpr int IP = IPMAX >= TM ? TM : (IPMAX >= TM / 2 && TM % 2 == 0) ? TM / 2 : (IPMAX >= TM / 4 && TM % 4 == 0) ? TM / 4 : 1;
@@ -383,12 +417,13 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm2_kernel(const GemmArgs p) 
         }
       }
       __builtin_amdgcn_wave_barrier();
-      for (int idx = lane; idx < IP * 16 * CPR; idx += 64) {
+      auto finish = [&](int idx, f32x4_t r, bool have_r) {   // row-segment chunk idx of this pass: residual, activation, store
         const int row = idx / CPR, ch = idx - row * CPR;
         const int m = mw + ps * IP * 16 + row, n = nw + ch * 4;
         f32x4_t v = *reinterpret_cast<const f32x4_t*>(slice + row * RS + ch * 16);
         if (m < p.M && n < p.N) {
-          if (Rf) v += *reinterpret_cast<const f32x4_t*>(Rf + out_row(m) * p.ldr + n);
+          if (have_r) v += r;
+          else if (Rf) v += *reinterpret_cast<const f32x4_t*>(Rf + out_row(m) * p.ldr + n);
           if (p.act == ACT_QUICK_GELU) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = quick_gelu_f(v[r]);
@@ -407,10 +442,16 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm2_kernel(const GemmArgs p) 
             *reinterpret_cast<f32x4_t*>(C + out_row(m) * p.ldc + n) = v;
           }
         }
+      };
+      if constexpr (RPRE) {
+#pragma unroll
+        for (int it = 0; it < E_IT; ++it) finish(lane + it * 64, rpre[ps * E_IT + it], true);
+      } else {
+        for (int idx = lane; idx < IP * 16 * CPR; idx += 64) finish(idx, (f32x4_t){0.f, 0.f, 0.f, 0.f}, false);
       }
       __builtin_amdgcn_wave_barrier();
     }
-  } else {
+  } else if constexpr (!RPRE) {
     constexpr int RS = WTN * 2 + 16;
     constexpr int IPMAX = (STAGES * STAGE / NW) / (16 * RS);
     constexpr int IP = IPMAX >= TM ? TM : (IPMAX >= TM / 2 && TM % 2 == 0) ? TM / 2 : (IPMAX >= TM / 4 && TM % 4 == 0) ? TM / 4 : 1;
@@ -500,20 +541,32 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
   }
 }
 
-template <typename T, int BM, int BN, int WGM, int WGN, int STAGES, bool CONV>
-static int launch2(GemmArgs& a, int batch, hipStream_t st) {
-  a.tiles_m = (a.M + BM - 1) / BM;
-  a.tiles_n = (a.N + BN - 1) / BN;
+template <typename T, int BM, int BN, int WGM, int WGN, int STAGES, bool CONV, int EPI>
+static int launch2_epi(GemmArgs& a, int batch, hipStream_t st) {
   constexpr int lds = STAGES * (BM + BN) * 128;
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)gemm2_kernel<T, BM, BN, WGM, WGN, STAGES, CONV>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)gemm2_kernel<T, BM, BN, WGM, WGN, STAGES, CONV, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
       return sdamd_set_error(2, "gemm2: cannot reserve %d bytes of LDS", lds);
     attr_set = true;
   }
   dim3 grid(a.tiles_m * a.tiles_n, batch, a.splits);
-  gemm2_kernel<T, BM, BN, WGM, WGN, STAGES, CONV><<<grid, WGM * WGN * 64, lds, st>>>(a);
+  gemm2_kernel<T, BM, BN, WGM, WGN, STAGES, CONV, EPI><<<grid, WGM * WGN * 64, lds, st>>>(a);
   SD_LAUNCH_CHECK("gemm2");
+  return 0;
+}
+
+template <typename T, int BM, int BN, int WGM, int WGN, int STAGES, bool CONV>
+static int launch2(GemmArgs& a, int batch, hipStream_t st) {
+  a.tiles_m = (a.M + BM - 1) / BM;
+  a.tiles_n = (a.N + BN - 1) / BN;
+  // residual-prefetch kernel (EPI 1): f32 residual + f32 / hi|lo output, no split, on the tiles with the registers for it
+  constexpr bool HAS_RPRE = WGM * WGN == 4 || (!CONV && BM == 128 && BN == 320);
+  if constexpr (HAS_RPRE) {
+    if (a.R && (sizeof(T) == 4 || a.out_f32) && a.splits == 1 && a.act != ACT_GEGLU)
+      return launch2_epi<T, BM, BN, WGM, WGN, STAGES, CONV, 1>(a, batch, st);
+  }
+  if (int e = launch2_epi<T, BM, BN, WGM, WGN, STAGES, CONV, 0>(a, batch, st)) return e;
   if (a.splits > 1) {
     GemmArgs r = a;
     if (sizeof(T) == 4) r.out_f32 = 1;   // f32 operands: C and the residual are f32

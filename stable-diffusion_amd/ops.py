@@ -85,10 +85,13 @@ def _timed(kind, work, launch, shape=""):
     return r
 
 
-def _tile_tag(M, N, K, dtype, ws, batch=1, act=0):
+def _tile_tag(M, N, K, dtype, ws, batch=1, act=0, f32_residual=False, conv=False):
+    """Profiler label of the kernel sdamd_gemm / sdamd_conv3x3 will pick: tile, split-K factor, and ``_rp`` for the
+    residual-prefetch instantiation (gemm2.hip launch2: f32 residual, no split, 128x160 or dense 128x320 tile)."""
     t = _lib.lib().sdamd_gemm_tile(M, N, K, batch, _code(dtype), ws.numel(), int(act))
     t, s = t % 1000000, t // 1000000 + 1
-    return f"{t // 1000}x{t % 1000}" + (f"_splitk{s}" if s > 1 else "")
+    rp = f32_residual and s == 1 and gemm_supports_act(ACT_GEGLU, torch.bfloat16, 256) and (t == 128160 or (t == 128320 and not conv))
+    return f"{t // 1000}x{t % 1000}" + (f"_splitk{s}" if s > 1 else "_rp" if rp else "")
 
 
 _gemm_ws = {}
@@ -423,7 +426,7 @@ def gemm(a, w, bias=None, residual=None, act=ACT_NONE, out_f32=False, out_hilo=F
     if bias is not None:
         assert bias.dtype == torch.float32 and bias.numel() == N and bias.is_contiguous()
     ws = _gemm_workspace(a.device)
-    _timed(f"gemm_{_dt(a.dtype)}_{_tile_tag(M, N, K, a.dtype, ws, 1, act)}" if PROFILER is not None else "", 2.0 * M * N * K,
+    _timed(f"gemm_{_dt(a.dtype)}_{_tile_tag(M, N, K, a.dtype, ws, 1, act, residual is not None and res_dtype == torch.float32)}" if PROFILER is not None else "", 2.0 * M * N * K,
            lambda: _lib.check(_lib.lib().sdamd_gemm(_p(a), _p(w), _p(out), _p(bias), _p(residual), M, N, K, lda, K, n_out, ldr, 1,
                                                     0, 0, 0, 0, int(act), _code(a.dtype), int(out_f32), _p(ws), ws.numel(),
                                                     _stream())),
@@ -481,7 +484,7 @@ def conv3x3(x, w, bias, residual=None, stride=1, pad_mode=0, upsample=False, act
         assert bias.dtype == torch.float32 and bias.numel() == Cout
     M = B * Ho * Wo
     ws = _gemm_workspace(x.device)
-    _timed(f"conv3x3_{_dt(x.dtype)}_{_tile_tag(M, Cout, 9 * Cin, x.dtype, ws)}" if PROFILER is not None else "", 2.0 * M * Cout * 9 * Cin,   # algorithmic (reference) FLOPs, also for the 4/9-MAC phase form
+    _timed(f"conv3x3_{_dt(x.dtype)}_{_tile_tag(M, Cout, 9 * Cin, x.dtype, ws, f32_residual=residual is not None and out.dtype == torch.float32, conv=True)}" if PROFILER is not None else "", 2.0 * M * Cout * 9 * Cin,   # algorithmic (reference) FLOPs, also for the 4/9-MAC phase form
            lambda: _lib.check(_lib.lib().sdamd_conv3x3(_p(x), _p(w), _p(out), _p(bias), _p(residual), B, H, W, Cin, Cout, stride,
                                                        pad_mode, upsample, int(act), _code(x.dtype), int(out_f32),
                                                        _p(ws), ws.numel(), _stream())),
