@@ -55,10 +55,11 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
 #endif
 
 // EPI 0: every epilogue (split-K partials, GeGLU, f32 / hi|lo, operand type), chosen at run time.
-// EPI 1: the f32 / hi|lo epilogue with an f32 residual only, the residual prefetched ahead of the K loop (a kernel
-// of its own: the other epilogues' code and the unrolled prefetch would otherwise sit in every launch's I-cache
-// footprint -- a first build with both in one kernel made the launches WITHOUT a residual 6-13 us slower in a
-// UNet step, where consecutive launches are different kernels, while a back-to-back microbenchmark saw nothing).
+// EPI 1: the f32 / hi|lo epilogue with an f32 residual only, the residual prefetched ahead of the K loop.
+// EPI 2: the GeGLU epilogue only (bf16).
+// (EPI 1 is a kernel of its own because a first build with the prefetch and every other epilogue in one kernel made
+// the launches WITHOUT a residual 6-13 us slower inside a UNet step, where consecutive launches are different
+// kernels, while a back-to-back microbenchmark saw nothing: code executed once per launch is not free.)
 template <typename T, int BM, int BN, int WGM, int WGN, int STAGES, bool CONV, int EPI>
 __global__ __launch_bounds__(WGM* WGN * 64) void gemm2_kernel(const GemmArgs p) {
   constexpr bool F32 = sizeof(T) == 4;     // exact-f32 MFMA (v_mfma_f32_16x16x4_f32) on f32 operands
@@ -327,7 +328,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm2_kernel(const GemmArgs p) 
   }
 #undef GEMM2_STEP
 
-  if (!RPRE && p.splits > 1) {  // raw f32 partial sums; bias / residual / activation happen in splitk_reduce_kernel
+  if (EPI == 0 && p.splits > 1) {  // raw f32 partial sums; bias / residual / activation happen in splitk_reduce_kernel
     float* __restrict__ ws = p.ws + (size_t)split * p.M * p.N;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -353,7 +354,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm2_kernel(const GemmArgs p) 
   __syncthreads();  // every wave is done reading the last K-tile (and no DMA is outstanding)
   const float* __restrict__ bias = p.bias;
   const int mw = m0 + wm * WTM, nw = n0 + wn * WTN;  // this wave's sub-tile origin
-  if (!RPRE && !F32 && p.act == ACT_GEGLU) {
+  if (EPI == 2 || (EPI == 0 && !F32 && p.act == ACT_GEGLU)) {
     // GeGLU epilogue (diffusion.py:128-130): the weight rows were packed so that 16-column tile 2c
     // holds the value channels [16c, 16c+16) and tile 2c+1 their gates; value * gelu_erf(gate) is
     // lane-local on the f32 accumulators and only the N/2 products are rounded and stored (bf16).
@@ -395,7 +396,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm2_kernel(const GemmArgs p) 
         __builtin_amdgcn_wave_barrier();
       }
     }
-  } else if (RPRE || F32 || p.out_f32) {
+  } else if (EPI != 2 && (RPRE || F32 || p.out_f32)) {
     constexpr int RS = WTN * 4 + 16;                     // padded LDS row stride (bytes)
     constexpr int IPMAX = (STAGES * STAGE / NW) / (16 * RS);  // 16-row tiles per pass that fit the wave's slice
     constexpr int IP = IPMAX >= TM ? TM : (IPMAX >= TM / 2 && TM % 2 == 0) ? TM / 2 : (IPMAX >= TM / 4 && TM % 4 == 0) ? TM / 4 : 1;
@@ -451,7 +452,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm2_kernel(const GemmArgs p) 
       }
       __builtin_amdgcn_wave_barrier();
     }
-  } else if constexpr (!RPRE) {
+  } else if constexpr (EPI == 0) {
     constexpr int RS = WTN * 2 + 16;
     constexpr int IPMAX = (STAGES * STAGE / NW) / (16 * RS);
     constexpr int IP = IPMAX >= TM ? TM : (IPMAX >= TM / 2 && TM % 2 == 0) ? TM / 2 : (IPMAX >= TM / 4 && TM % 4 == 0) ? TM / 4 : 1;
@@ -565,6 +566,9 @@ static int launch2(GemmArgs& a, int batch, hipStream_t st) {
   if constexpr (HAS_RPRE) {
     if (a.R && (sizeof(T) == 4 || a.out_f32) && a.splits == 1 && a.act != ACT_GEGLU)
       return launch2_epi<T, BM, BN, WGM, WGN, STAGES, CONV, 1>(a, batch, st);
+  }
+  if constexpr (sizeof(T) == 2 && !CONV && (BN / WGN / 16) % 2 == 0) {
+    if (a.act == ACT_GEGLU) return launch2_epi<T, BM, BN, WGM, WGN, STAGES, CONV, 2>(a, batch, st);
   }
   if (int e = launch2_epi<T, BM, BN, WGM, WGN, STAGES, CONV, 0>(a, batch, st)) return e;
   if (a.splits > 1) {
