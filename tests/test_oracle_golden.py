@@ -261,3 +261,18 @@ def test_pipeline_txt2img_without_cfg(model_sds, diffusion_sd):
         assert rel_l2(trace[i], g["latents"][i]) < TOL_MODEL, i
     diff = np.abs(img.astype(np.int32) - g["image"].astype(np.int32))
     assert diff.max() <= 1 and (diff > 0).mean() < 0.01
+
+
+@pytest.mark.slow
+def test_reference_fp16_mode_deviation(model_sds, diffusion_sd):
+    """fp16_enabled=True (pipeline.py:124-139): the reference's own fp16-autocast run next to its fp32 run
+    of the same 2 steps.  The oracle (fp32) reproduces the fp32 golden; the fp16 golden deviates from it by ~1.5e-2
+    per step -- the yardstick for the product's reduced-precision mode (tests/test_hip_models.py)."""
+    g32, g16 = golden("pipeline_txt2img_2step"), golden("pipeline_txt2img_fp16_2step")
+    models = dict(model_sds, diffusion=diffusion_sd)
+    trace = []
+    O.generate(models, synth.synthetic_token_ids(0), synth.EMPTY_PROMPT_IDS, seed=42, steps=2, trace=trace)
+    for i in range(2):
+        assert rel_l2(trace[i], g32["latents"][i]) < TOL_MODEL, i
+        dev = rel_l2(g16["latents"][i], g32["latents"][i])
+        assert 5e-3 < dev < 3e-2, (i, dev)

@@ -6,7 +6,7 @@ imports the reference's modules unmodified, fills them with the hash weights of
 ``stable-diffusion_amd/synth.py`` (same state_dict keys), feeds hash/seeded inputs and
 stores the outputs.  Fixtures are data only -- no reference source is copied.
 
-    python tools/gen_golden.py [keys] [small] [models] [pipe3] [img2img] [pipe50] [converter] [ddim] [nocfg] [euler]
+    python tools/gen_golden.py [keys] [small] [models] [pipe3] [img2img] [pipe50] [converter] [ddim] [nocfg] [euler] [fp16]
 """
 import contextlib
 import io
@@ -344,6 +344,9 @@ def main():
         gen_converter()
     if "nocfg" in what:      # pipeline.py:66-70,136-137,150-151: no guidance, context = the prompt alone
         gen_pipeline(2, "pipeline_txt2img_nocfg_2step", do_cfg=False)
+    if "fp16" in what:       # pipeline.py:124-139: the reference's own reduced-precision mode (fp16 autocast), on CPU
+        gen_pipeline(2, "pipeline_txt2img_fp16_2step", fp16_enabled=True)
+        gen_pipeline(2, "pipeline_txt2img_2step")     # the same run in fp32: what the fp16 mode deviates from
     if "pipe50" in what:
         gen_pipeline(50, "pipeline_txt2img_50step", every=1)
 
