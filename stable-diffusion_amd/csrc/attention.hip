@@ -72,6 +72,12 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs p) {
   // P V product itself accumulates the softmax denominator (from the same rounded P as the
   // numerator) and the online rescale of O covers it: no per-score adds, no cross-half exchange.
   constexpr bool ONES = D < DV;
+  // When the head dim also leaves a spare padded K column (d = 40: DK = 48), the softmax reference rides in the QK^T
+  // product: Q is pre-scaled by scale*log2(e) once, K[:, D] = 1 and Q[:, D] = -m (the query's current reference, kept
+  // bf16-exact), so the MFMA returns scale*s - m and exp2 applies to it directly -- no per-score FMA (16 v_pk_fma_f32
+  // of the 131 VALU instructions per 64-key tile in a VALU-issue-bound loop).  The reference still only moves when a
+  // row outgrows it by 2^RESCALE_THR; tiles where it moves subtract the difference explicitly (rare path).
+  constexpr bool AUG = BF && DK > D && ONES;
   constexpr int L_BLK = D / 32, L_REG = ((D % 32) & 3) + 4 * ((D % 32) >> 3), L_HALF = ((D % 32) >> 2) & 1;
   constexpr int NQ = BF ? DK / 16 : D / 8;                   // Q fragments (4 VGPR each)
   constexpr int KCH = BKV * KC, VCH = BKV * VC;              // chunks per staged tile
@@ -106,6 +112,16 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs p) {
     for (int s = 0; s < NQ; ++s)
 #pragma unroll
       for (int j = 0; j < 4; ++j) asm volatile("v_mov_b32 %0, %1" : "=v"(qf[s][j]) : "v"(qf[s][j]));
+    if constexpr (AUG) {   // Q *= scale*log2(e), rounded to bf16 once per query element
+#pragma unroll
+      for (int s = 0; s < NQ; ++s)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float lo = __builtin_bit_cast(float, qf[s][j] << 16) * p.scale_log2e;
+          const float hi = __builtin_bit_cast(float, qf[s][j] & 0xffff0000u) * p.scale_log2e;
+          qf[s][j] = pack_bf2(lo, hi);
+        }
+    }
   }
 
   // Register-staged K/V tile: the loads of tile t+1 are issued before tile t is computed and written
@@ -147,6 +163,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs p) {
     const int row = srow % BKV;
     u32x4_t z = {0u, 0u, 0u, 0u};
     if (pc < KC - DC) {
+      if (AUG && pc == 0) z[0] = 0x00003F80u;                        // K[:, D] = 1: carries Q[:, D] = -m into every score
       *reinterpret_cast<u32x4_t*>(base + row * KS + (DC + pc) * 16) = z;
     } else {
       const int ch = DC + pc - (KC - DC);
@@ -160,7 +177,8 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs p) {
   for (int i = 0; i < NB; ++i)
 #pragma unroll
     for (int e = 0; e < 16; ++e) o[i][e] = 0.f;
-  float m_run = -1.0e30f, l_run = 0.f;  // running max (scaled, log2 domain) and denominator
+  float m_run = AUG ? 0.f : -1.0e30f, l_run = 0.f;  // running max (scaled, log2 domain) and denominator
+  float m_qk = 0.f;                                    // AUG: the reference currently baked into Q[:, D]
 
   // causal: this block needs keys 0 .. q0_block+127 only
   int kv_end = p.Skv;
@@ -215,6 +233,28 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) mx = fmaxf(mx, s[sub][e]);
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      if constexpr (AUG) {
+        // s = scale*score - m_qk already.  The first sub-tile of the row sets the reference outright (it starts at 0,
+        // which may be far above every score); afterwards it moves only when outgrown by RESCALE_THR.
+        const float off = m_run - m_qk;                              // what the baked-in reference is short of the current one
+        const float rel = mx - off;                                  // row maximum relative to the current reference
+        const bool first = kt == 0 && sub == 0;
+        if (first || !__all(off == 0.f && rel <= RESCALE_THR)) {     // rare: some row of this wave moves (or has moved) its reference
+          const float m_new = (first || rel > RESCALE_THR) ? bf2f(f2bf(m_run + rel)) : m_run;
+          const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+          const float shift = m_new - m_qk;
+#pragma unroll
+          for (int e = 0; e < 16; ++e) s[sub][e] -= shift;
+          m_run = m_new;
+#pragma unroll
+          for (int i = 0; i < NB; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) o[i][e] *= alpha;
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) s[sub][e] = __builtin_amdgcn_exp2f(s[sub][e]);
+        return;
+      }
       // Lazy running max: the reference point m only moves when a row's maximum outgrows it by more
       // than RESCALE_THR (log2 units), so P stays <= 2^THR and the O rescale below is rare.  Exact in
       // exact arithmetic (numerator and denominator carry the same factor); P is a float either way.
@@ -289,6 +329,13 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs p) {
       if (!ATTN_DBG(2)) pv(sub);
     }
 
+    if constexpr (AUG) {
+      if (!__all(m_run == m_qk)) {   // the reference moved in this tile: Q[:, D] = -m for the next one (lanes of half 1 hold column D)
+        const unsigned nm = __builtin_bit_cast(unsigned, -m_run) >> 16;      // m_run is bf16-exact
+        if (h == 1) qf[NQ - 1][0] = (qf[NQ - 1][0] & 0xffff0000u) | nm;
+        m_qk = m_run;
+      }
+    }
     if (kt + 1 < ntiles && !ATTN_DBG(4) && !ATTN_DBG(5)) commit((kt + 1) & 1);
     if (!ATTN_DBG(5)) __syncthreads();
   }
