@@ -195,7 +195,8 @@ def test_gather_row_and_silu():
 @pytest.mark.parametrize("B,C,H,W,eps,silu", [
     (2, 320, 16, 16, 1e-5, True), (2, 320, 8, 8, 1e-6, False), (1, 2560, 8, 8, 1e-5, True),
     (2, 1920, 4, 4, 1e-5, True), (1, 960, 16, 16, 1e-5, True), (1, 128, 32, 32, 1e-5, True),
-    (3, 64, 2, 2, 1e-5, False), (1, 512, 64, 64, 1e-5, True), (1, 1280, 1, 1, 1e-5, True)])
+    (3, 64, 2, 2, 1e-5, False), (1, 512, 64, 64, 1e-5, True), (1, 1280, 1, 1, 1e-5, True),
+    (2, 640, 16, 16, 1e-5, True), (1, 1280, 8, 8, 1e-6, False), (2, 2560, 8, 8, 1e-5, True), (2, 1280, 16, 16, 1e-5, True)])   # around the one-launch limit
 def test_groupnorm(dtype, B, C, H, W, eps, silu):
     x = q(rnd(f"gn.{C}.{H}", (B, C, H, W), 2.0) + 0.5, dtype)
     gamma, beta = rnd(f"gn.g.{C}", (C,), 0.2) + 1.0, rnd(f"gn.b.{C}", (C,), 0.2)
