@@ -8,8 +8,6 @@ Activation layout is NHWC / token-major: [B, H, W, C] or [B, S, C], float32 or b
 """
 import math
 
-import os
-
 import torch
 
 from . import _lib
@@ -386,8 +384,6 @@ def vae_sample(moments, noise, w, b):
 def gemm_hilo_fused(M, N, K, dtype):
     """True when sdamd_gemm can emit its result directly as the bf16 hi|lo pair (out_f32 = 2)."""
     if dtype != torch.bfloat16 or not gemm_supports_act(ACT_GEGLU, dtype, 256):    # 4-wave kernels forced
-        return False
-    if os.environ.get("SDAMD_NO_HILO_FUSE"):     # experiments/ab_bench.sh: A/B against a library without it
         return False
     tile = _lib.lib().sdamd_gemm_tile(M, N, K, 1, _code(dtype), GEMM_WS_BYTES, 0) % 1000000
     return tile in (128160, 128320, 256256)      # the LDS-DMA tiles (gemm2.hip); the 4-wave ones have no such epilogue
