@@ -631,10 +631,12 @@ int gemm2_choose_tile(int M, int N, int K, int batch, int mode, size_t ws_bytes,
   }
   if (N % 160 == 0) {
     // 4-wave tile, two workgroups per CU: aim at >= 512 workgroups, splitting K up to 4 ways while
-    // every split keeps >= 16 K-tiles (measured: 16x16 maps S=2 607->832 TF, 8x8 maps S=4 174->484 TF)
+    // every split keeps >= 16 K-tiles (measured: 16x16 maps S=2 607->832 TF, 8x8 maps S=4 174->484 TF), up to 8
+    // ways on the long-K convs (K >= 8192; in situ the 8x8-level convs S=4 -> 8: 483 -> 539 TF at K=11520,
+    // 565 -> 658 TF at K=23040, while the K=5120 GEMMs lose with S=5)
     const long long b = blocks(128, 160);
     int s = (int)((512 + b - 1) / b);
-    if (s > 4) s = 4;
+    if (s > (nk >= 128 ? 8 : 4)) s = nk >= 128 ? 8 : 4;
     if (s > nk / 16) s = nk / 16;
     if (s > max_splits()) s = max_splits();
     if (s >= 2) { *splits = s; return 128160; }
