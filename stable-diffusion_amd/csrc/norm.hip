@@ -304,28 +304,32 @@ extern "C" size_t sdamd_groupnorm_ws_bytes(int B) { return (size_t)B * (64 * 32 
 
 // GroupNorm of a small map in ONE launch: one workgroup per (sample, group) keeps the group's HW x C/32 elements in
 // registers (pairs of channels, <= GNG_MAXP pairs per thread), so statistics and normalisation need no second pass over
-// memory and no second kernel.  Only for the smallest maps (a group of <= 5120 elements: the 8x8 level of the UNet),
-// where it saves 7-8 us per call; measured with GNG_MAXP = 40 the 16x16 and 32x32 levels were 10-30 % SLOWER than the
-// two-launch form (512 workgroups, each a serial load -> reduce -> reduce -> store chain), so they keep that form.
+// memory and no second kernel.  Only for small maps (a group of <= 10240 elements: the 8x8 level of the UNet with 256
+// threads, the un-concatenated 16x16 level with 512), where it saves 5-8 us per call; with more work per workgroup
+// (40 pairs per thread, or 1024 threads on the 32x32 level) it measured 10-30 % SLOWER than the two-launch form
+// (512 workgroups, each a serial load -> reduce -> reduce -> store chain), so larger groups keep that form.
 // Two-pass variance in f32 (mean first, then the centred squares).
 constexpr int GNG_MAXP = 10;
 typedef __attribute__((ext_vector_type(2))) float f32x2_t;
-template <typename T, typename TO>
-__global__ __launch_bounds__(256) void gn_group_kernel(const T* __restrict__ x, const T* __restrict__ x2, int C1,
+template <typename T, typename TO, int NT>
+__global__ __launch_bounds__(NT) void gn_group_kernel(const T* __restrict__ x, const T* __restrict__ x2, int C1,
                                                        TO* __restrict__ y, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, float eps, int HW, int C, int silu) {
-  __shared__ float s_red[8];
+  __shared__ float s_red[NT / 64];
   const int n = blockIdx.y, g = blockIdx.x, t = threadIdx.x;
   const int cpg = C / 32, ppp = cpg >> 1;           // channels per group, channel pairs per pixel
   const int items = HW * ppp, c_base = g * cpg;
-  const int dp = 256 / ppp, dc = 256 % ppp;
+  const int dp = NT / ppp, dc = NT % ppp;
   auto block_sum = [&](float a) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
     __syncthreads();                                  // (s_red may still be read from the previous call)
     if ((t & 63) == 0) s_red[t >> 6] = a;
     __syncthreads();
-    return s_red[0] + s_red[1] + s_red[2] + s_red[3];
+    float tot = 0.f;
+#pragma unroll
+    for (int w = 0; w < NT / 64; ++w) tot += s_red[w];
+    return tot;
   };
   float v[GNG_MAXP][2];
   float sum = 0.f;
@@ -334,7 +338,7 @@ __global__ __launch_bounds__(256) void gn_group_kernel(const T* __restrict__ x, 
 #pragma unroll
     for (int k = 0; k < GNG_MAXP; ++k) {
       v[k][0] = v[k][1] = 0.f;
-      if (t + 256 * k < items) {
+      if (t + NT * k < items) {
         const int c = c_base + 2 * pc;
         const T* src = !x2 ? x + ((size_t)n * HW + px) * C + c
                            : c < C1 ? x + ((size_t)n * HW + px) * C1 + c : x2 + ((size_t)n * HW + px) * (C - C1) + (c - C1);
@@ -356,13 +360,13 @@ __global__ __launch_bounds__(256) void gn_group_kernel(const T* __restrict__ x, 
   float sq = 0.f;
 #pragma unroll
   for (int k = 0; k < GNG_MAXP; ++k)
-    if (t + 256 * k < items) { const float a = v[k][0] - mean, b = v[k][1] - mean; sq += a * a + b * b; }
+    if (t + NT * k < items) { const float a = v[k][0] - mean, b = v[k][1] - mean; sq += a * a + b * b; }
   const float rstd = 1.0f / sqrtf(block_sum(sq) / cnt + eps);
   {
     int px = t / ppp, pc = t - px * ppp;
 #pragma unroll
     for (int k = 0; k < GNG_MAXP; ++k) {
-      if (t + 256 * k < items) {
+      if (t + NT * k < items) {
         const int c = c_base + 2 * pc;
         const f32x2_t ga = *reinterpret_cast<const f32x2_t*>(gamma + c), be = *reinterpret_cast<const f32x2_t*>(beta + c);
         float r[2];
@@ -392,14 +396,16 @@ static int groupnorm_impl(const void* x, const void* x2, int C1, void* y, const 
   hipStream_t st = (hipStream_t)stream;
   {   // small maps: one launch, one workgroup per (sample, group)
     const int cpg = C / 32;
-    if (cpg % 2 == 0 && (long long)HW * (cpg / 2) <= 256LL * GNG_MAXP && (!x2 || C1 % 2 == 0)) {
+    const long long items = (long long)HW * (cpg / 2);
+    if (cpg % 2 == 0 && items <= 512LL * GNG_MAXP && (!x2 || C1 % 2 == 0)) {
       dim3 gg(32, B);
-      if (dtype == SDAMD_BF16)
-        gn_group_kernel<bf16_t, bf16_t><<<gg, 256, 0, st>>>((const bf16_t*)x, (const bf16_t*)x2, C1, (bf16_t*)y, gamma, beta, eps, HW, C, silu);
-      else if (out_dtype == SDAMD_BF16)
-        gn_group_kernel<float, bf16_t><<<gg, 256, 0, st>>>((const float*)x, (const float*)x2, C1, (bf16_t*)y, gamma, beta, eps, HW, C, silu);
-      else
-        gn_group_kernel<float, float><<<gg, 256, 0, st>>>((const float*)x, (const float*)x2, C1, (float*)y, gamma, beta, eps, HW, C, silu);
+#define GNG(TT, TTO, NT) gn_group_kernel<TT, TTO, NT><<<gg, NT, 0, st>>>((const TT*)x, (const TT*)x2, C1, (TTO*)y, gamma, beta, eps, HW, C, silu)
+#define GNG_T(TT, TTO) { if (items <= 256LL * GNG_MAXP) GNG(TT, TTO, 256); else GNG(TT, TTO, 512); }
+      if (dtype == SDAMD_BF16) GNG_T(bf16_t, bf16_t)
+      else if (out_dtype == SDAMD_BF16) GNG_T(float, bf16_t)
+      else GNG_T(float, float)
+#undef GNG_T
+#undef GNG
       SD_LAUNCH_CHECK("gn_group");
       return 0;
     }
