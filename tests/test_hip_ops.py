@@ -397,6 +397,23 @@ def test_conv3x3(dtype, B, Cin, Cout, H, W, stride, pad_mode, ups, res, gemm_imp
     assert rel_l2(from_nhwc(got), want.float()) < tol(dtype, 2e-6, 4e-3)
 
 
+def test_conv3x3_long_k_auto_split():
+    """The 8x8-level UNet conv (M = 128 at UNet batch 2, K = 9*1280): the planner's own choice there is the 128x160 tile
+    with an 8-way K split; bf16 operands, f32 residual and output."""
+    from sd_amd import _lib
+    B, C, H = 2, 1280, 8
+    ws = ops._gemm_workspace(torch.device(DEV))
+    t = _lib.lib().sdamd_gemm_tile(B * H * H, C, 9 * C, 1, 1, ws.numel(), 0)   # dtype 1 = SDAMD_BF16
+    assert (t % 1000000, t // 1000000 + 1) == (128160, 8)
+    x = rnd("conv.lk.x", (B, C, H, H)).bfloat16().float()
+    w = (rnd("conv.lk.w", (C, C, 3, 3)) * (9 * C) ** -0.5).bfloat16().float()
+    b, r = rnd("conv.lk.b", (C,)), rnd("conv.lk.r", (B, C, H, H), 2.0)
+    want = F.conv2d(x.double(), w.double(), b.double(), padding=1).float() + r
+    wp = w.permute(0, 2, 3, 1).reshape(C, -1).contiguous().bfloat16().to(DEV)
+    got = ops.conv3x3(to_nhwc(x, torch.bfloat16), wp, b.to(DEV), to_nhwc(r, torch.float32), out_f32=True)
+    assert got.dtype == torch.float32 and rel_l2(from_nhwc(got), want) < 2e-5
+
+
 @pytest.mark.parametrize("B,C,Cout,H,W,dup", [(2, 64, 320, 8, 8, 1), (1, 128, 160, 5, 7, 1), (2, 64, 320, 4, 4, 2)])
 def test_conv3x3_upsample_phase_form(B, C, Cout, H, W, dup):
     """nearest-2x + conv3x3 as four 2x2 phase convs (4/9 of the MACs) == the gathered form."""
