@@ -95,7 +95,8 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm2_kernel(const GemmArgs p) 
   // (y-(1-py), x-(1-px)), with the 3x3 taps that land on the same input pixel pre-summed on the host:
   // 4/9 of the MACs.  Rows m index the LOW-resolution grid; out_row() maps them to the output.
   const bool phase_up = CONV && EPI == 0 && p.phase_up;   // (the phase form never carries a residual)
-  const int py = phase_up ? (batch >> 1) : 0, px = phase_up ? (batch & 1) : 0;
+  const int phase = batch + p.phase_base;
+  const int py = phase_up ? (phase >> 1) : 0, px = phase_up ? (phase & 1) : 0;
   const int ntx = phase_up ? 2 : 3;                       // taps per filter row
   auto out_row = [&](int m) -> size_t {
     if (!phase_up) return (size_t)m;
@@ -505,10 +506,17 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
   const size_t total = (size_t)p.M * nq;
   const size_t slab = (size_t)p.M * p.N;
   for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
-    const size_t m = idx / nq;
-    const int n = (int)(idx - m * nq) << 2;
-    f32x4_t v = *reinterpret_cast<const f32x4_t*>(p.ws + m * p.N + n);
-    for (int s = 1; s < p.splits; ++s) v += *reinterpret_cast<const f32x4_t*>(p.ws + s * slab + m * p.N + n);
+    const size_t m_in = idx / nq;
+    const int n = (int)(idx - m_in * nq) << 2;
+    f32x4_t v = *reinterpret_cast<const f32x4_t*>(p.ws + m_in * p.N + n);
+    size_t m = m_in;                       // output row: the low-resolution row itself, or its place in phase (py, px)
+    if (p.phase_up) {
+      const int hw = p.Ho * p.Wo;
+      const int n_img = (int)(m_in / hw), rem = (int)(m_in - (size_t)n_img * hw);
+      const int y = rem / p.Wo, x = rem - y * p.Wo;
+      m = ((size_t)n_img * 2 * p.Ho + 2 * y + (p.phase_base >> 1)) * (2 * p.Wo) + 2 * x + (p.phase_base & 1);
+    }
+    for (int s = 1; s < p.splits; ++s) v += *reinterpret_cast<const f32x4_t*>(p.ws + s * slab + m_in * p.N + n);
     if (p.bias) v += *reinterpret_cast<const f32x4_t*>(p.bias + n);
     if (p.R) {
       if (p.out_f32) {

@@ -20,6 +20,7 @@ struct GemmArgs {
   // conv geometry (CONV only)
   int H, Wd, Cin, Ho, Wo, stride, pad, ups;
   int phase_up;  // 1: nearest-2x upsample + conv3x3 as four 2x2 convs, grid.y = output phase (py, px); see sdamd_conv3x3
+  int phase_base;  // phase_up: added to grid.y to give the phase (one launch per phase when the phases are K-split)
   int tiles_m, tiles_n;
   // split-K (gemm2.hip): grid.z = splits, each writes raw f32 partials to ws[split][M][N]
   int splits;

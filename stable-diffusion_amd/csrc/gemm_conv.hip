@@ -496,6 +496,26 @@ extern "C" int sdamd_conv3x3(const void* x, const void* w, void* y, const float*
     a.splits = 1; a.ws = nullptr; a.ws_bytes = 0; a.debug = g_gemm_debug;
     a.H = H; a.Wd = Wd; a.Cin = Cin; a.Ho = H; a.Wo = Wd; a.stride = 1; a.pad = 1; a.ups = 0; a.phase_up = 1;
     if (int e = check_common(a, dtype, "conv3x3")) return e;
+    // Few low-resolution rows (UNet batch 2: 8x8 .. 32x32 maps): four phases of a handful of tiles leave the chip idle
+    // and a batched launch cannot split K.  Then each phase is a launch of its own with the planner's K split and the
+    // reduce kernel placing the rows (fp32 UNet batch 2: the three upsample convs 1.62 -> ~0.6 ms per step).
+    if (g_gemm_impl != 1 && ws && 4LL * ((a.M + 127) / 128) * ((a.N + 159) / 160) < 256) {   // (256 workgroups fill the chip once: measured, 256 keep the batched launch)
+      int splits = 1;
+      const int tile = gemm2_choose_tile(a.M, a.N, a.K, 1, g_gemm_impl, ws_bytes, &splits, dtype == SDAMD_BF16 ? 64 : 32);
+      if (tile && splits > 1) {
+        const size_t esz = dtype == SDAMD_BF16 ? 2 : 4;
+        for (int ph = 0; ph < 4; ++ph) {
+          GemmArgs b = a;
+          b.W = (const char*)w + (size_t)ph * a.sW * esz;
+          b.phase_base = ph;
+          b.ws = (float*)ws; b.ws_bytes = ws_bytes;
+          const int r = launch_gemm2(b, dtype, 1, true, g_gemm_impl, st);
+          SD_CHECK(r >= 0, "conv3x3: phase launch failed for Cout=%d", Cout);
+          if (r) return r;
+        }
+        return 0;
+      }
+    }
     int r = launch_gemm2(a, dtype, 4, true, g_gemm_impl, st);
     if (r < 0) r = launch_gemm2(a, dtype, 4, true, 2, st);   // few workgroups: any tile that divides Cout
     SD_CHECK(r >= 0, "conv3x3: no 8-wave tile divides Cout=%d", Cout);

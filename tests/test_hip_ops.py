@@ -414,7 +414,8 @@ def test_conv3x3_long_k_auto_split():
     assert got.dtype == torch.float32 and rel_l2(from_nhwc(got), want) < 2e-5
 
 
-@pytest.mark.parametrize("B,C,Cout,H,W,dup", [(2, 64, 320, 8, 8, 1), (1, 128, 160, 5, 7, 1), (2, 64, 320, 4, 4, 2)])
+@pytest.mark.parametrize("B,C,Cout,H,W,dup", [(2, 64, 320, 8, 8, 1), (1, 128, 160, 5, 7, 1), (2, 64, 320, 4, 4, 2),
+                                              (1, 640, 320, 8, 8, 2)])    # last: few rows, long K -> one K-split launch per phase
 def test_conv3x3_upsample_phase_form(B, C, Cout, H, W, dup):
     """nearest-2x + conv3x3 as four 2x2 phase convs (4/9 of the MACs) == the gathered form."""
     from sd_amd import engine
@@ -430,6 +431,23 @@ def test_conv3x3_upsample_phase_form(B, C, Cout, H, W, dup):
     got = ops.conv3x3(xin, wp, engine.f32(conv.bias), None, 1, 0, 2, out_f32=True)
     assert tuple(got.shape) == (B, 2 * H, 2 * W, Cout)
     assert rel_l2(from_nhwc(got), want) < (2e-3 if dup == 2 else 4e-3)
+
+
+def test_conv3x3_upsample_phase_form_f32_split():
+    """fp32 UNet batch 2, the 16x16 -> 32x32 upsample conv: each phase is a launch of its own with an 8-way K split."""
+    from sd_amd import engine, _lib
+    B, C, H = 2, 1280, 16
+    ws = ops._gemm_workspace(torch.device(DEV))
+    t = _lib.lib().sdamd_gemm_tile(B * H * H, C, 4 * C, 1, 0, ws.numel(), 0)
+    assert t // 1000000 + 1 > 1
+    conv = torch.nn.Conv2d(C, C, 3, padding=1)
+    synth.load_hashed(conv, "ops.upphase.f32.")
+    x = rnd("upphase.f32.x", (B, C, H, H))
+    want = conv(F.interpolate(x, scale_factor=2, mode="nearest"))
+    conv.to(DEV)
+    wp = engine.conv3x3_up_phase_w(conv, torch.float32, 1)
+    got = ops.conv3x3(to_nhwc(x, torch.float32), wp, engine.f32(conv.bias), None, 1, 0, 2)
+    assert tuple(got.shape) == (B, 2 * H, 2 * H, C) and rel_l2(from_nhwc(got), want) < 5e-6
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
