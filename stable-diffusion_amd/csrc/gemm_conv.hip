@@ -363,14 +363,15 @@ static int launch_gemm(GemmArgs& a, int batch, hipStream_t st) {
     attr_set = true;
   }
   // split-K for the parallelism-starved shapes (fp32 UNet at batch 2: M = 128 .. 2048 with K up to
-  // 23040 leaves most CUs idle): aim at >= 512 workgroups, keep >= 8 K-tiles per split
+  // 23040 leaves most CUs idle): aim at >= 512 workgroups with up to 16 splits (8 -> 16 on the 8x8-level convs of the
+  // fp32 UNet at batch 2: -7...-10 % in situ), keep >= 8 K-tiles per split
   a.splits = 1;
   const long long blocks = (long long)a.tiles_m * a.tiles_n * batch;
   const int nk = a.K / (int)(128 / sizeof(T));
   const size_t slab = (size_t)a.M * a.N * sizeof(float);
   if (batch == 1 && a.ws && blocks < 256 && nk >= 16 && a.ldr % 4 == 0 && a.ldc % 4 == 0) {
     long long s = (512 + blocks - 1) / blocks;
-    if (s > 8) s = 8;
+    if (s > 16) s = 16;
     if (s > nk / 8) s = nk / 8;
     if (s * slab > a.ws_bytes) s = (long long)(a.ws_bytes / slab);
     if (s >= 2) a.splits = (int)s;
