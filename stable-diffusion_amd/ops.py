@@ -84,12 +84,13 @@ def _timed(kind, work, launch, shape=""):
 
 
 def _tile_tag(M, N, K, dtype, ws, batch=1, act=0, f32_residual=False, conv=False):
-    """Profiler label of the kernel sdamd_gemm / sdamd_conv3x3 will pick: tile, split-K factor, and ``_rp`` for the
-    residual-prefetch instantiation (gemm2.hip launch2: f32 residual, no split, 128x160 or dense 128x320 tile)."""
+    """Profiler label of the kernel sdamd_gemm / sdamd_conv3x3 will pick: tile, split-K factor, and ``_rp`` / ``_geglu``
+    for the residual-prefetch (gemm2.hip launch2: f32 residual, no split, 128x160 or dense 128x320 tile) and GeGLU-only
+    epilogue instantiations."""
     t = _lib.lib().sdamd_gemm_tile(M, N, K, batch, _code(dtype), ws.numel(), int(act))
     t, s = t % 1000000, t // 1000000 + 1
     rp = f32_residual and s == 1 and gemm_supports_act(ACT_GEGLU, torch.bfloat16, 256) and (t == 128160 or (t == 128320 and not conv))
-    return f"{t // 1000}x{t % 1000}" + (f"_splitk{s}" if s > 1 else "_rp" if rp else "")
+    return f"{t // 1000}x{t % 1000}" + (f"_splitk{s}" if s > 1 else "_rp" if rp else "_geglu" if int(act) == ACT_GEGLU and t != 0 else "")
 
 
 _gemm_ws = {}

@@ -105,3 +105,23 @@ def test_product_never_imports_the_oracle():
                 for line in open(os.path.join(dirpath, f)):
                     if re.match(r"\s*(from|import)\s", line):
                         assert "oracle" not in line, (f, line)
+
+
+def test_bench_labels_map_to_kernel_symbols():
+    """bench.py attributes profiler labels to rocprofv3 kernel names (roofline object, PMC traffic lookup): the last
+    template argument of gemm2_kernel is its epilogue instantiation (1 = residual prefetch, label suffix _rp)."""
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    ks = bench.kernel_symbol
+    assert ks("conv3x3_bf16_128x160") == "gemm2_kernel<unsigned short, 128, 160, 2, 2, 2, true, 0>"
+    assert ks("conv3x3_bf16_128x160_splitk2") == "gemm2_kernel<unsigned short, 128, 160, 2, 2, 2, true, 0>"
+    assert ks("conv3x3_bf16_128x160_rp") == "gemm2_kernel<unsigned short, 128, 160, 2, 2, 2, true, 1>"
+    assert ks("gemm_bf16_128x320_rp") == "gemm2_kernel<unsigned short, 128, 320, 2, 4, 2, false, 1>"
+    assert ks("gemm_bf16_256x256_geglu") == "gemm2_kernel<unsigned short, 256, 256, 2, 4, 2, false, 2>"
+    assert ks("gemm_f32_128x160") == "gemm2_kernel<float, 128, 160, 2, 2, 2, false, 0>"
+    assert ks("gemm_f32_64x64") == "gemm_kernel<float, 64, 64, false>"
+    assert ks("attention_bf16_d40") == "attn_kernel<unsigned short, 40>"
+    assert ks("groupnorm_f32") == "groupnorm_f32"
+    traffic = bench.pmc_traffic("gemm2_kernel<unsigned short, 128, 160, 2, 2, 2, true, 0>")
+    assert traffic is None or traffic > 1e8        # profiles/r01_pmc_traffic.json carries the dominant kernel under this name
