@@ -2,6 +2,7 @@
 """Headline benchmark: images/sec @512x512, 50-step DDPM + CFG (BASELINE.json), one process per GPU.
 
     python bench.py --gpus 1 --steps 2 --warmup 1
+    python bench.py --gpus N ...            (plain python: spawns its own N ranks through torch.distributed.run)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -12,124 +13,29 @@ per GPU); weak scaling: every GPU does its own 8 images.  Token ids, noise and w
 in HBM before the timed region; weight hashing / repacking / graph capture happen in warm-up.
 
 Rank 0 prints ONE JSON line.  Besides the contract keys it carries
-  roofline      the dominant kernel family of the timed workload, timed live with HIP events on
-                the launch stream in one extra eager (un-graphed) pass of the same step,
-  cpu_baseline  the CPU oracle (oracle/sd_oracle.py, a port) timed on this host's cores on a
-                bounded sample (1 UNet step + 1 VAE decode + 2 CLIP encodes) and extrapolated,
-  extra         UNet step latencies (bf16 at the bench batch, fp32 at UNet batch 2 = config 2)
-                and the per-kernel-family breakdown.
+  roofline      the dominant kernel symbol of the timed workload, timed live with HIP events on the launch stream
+                in one extra eager (un-graphed) pass of the same step; FLOPs are the REFERENCE op's,
+  cpu_baseline  the CPU oracle (oracle/sd_oracle.py, a port) timed on this host's cores on a bounded sample of
+                BASELINE config 1 (2 UNet steps + 1 VAE decode + 2 CLIP encodes), with and without the reference's
+                per-step preview decode, CPU model and thread count stated,
+  extra         wall(pipeline.generate(...)) for the same batch (host noise draw + upload included), UNet step
+                latencies (median of 20 after 3 warm-ups: bf16 at the bench batch, bf16 and fp32 at UNet batch 2 =
+                config 2) and the per-kernel-family breakdown.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import sd_amd  # noqa: E402,F401
-from sd_amd import clip, decoder, diffusion, distributed, engine, ops, pipeline, synth  # noqa: E402
-
 PEAK = {"bf16": 2500.0, "f32": 157.3, "hbm": 8000.0}  # MI355X_MICROARCH.md: dense TFLOP/s, GB/s
 GFLOP_PER_IMAGE = 82866.0                              # SURVEY.md §8d: 50 x 1606.5 + 2514.5 + 26.6
-
-
-def build_models(device, dtype, keep_cpu):
-    torch.set_grad_enabled(False)
-    specs = (("clip", clip.CLIP), ("decoder", decoder.VAE_Decoder), ("diffusion", diffusion.Diffusion))
-    models, cpu_sd = {}, {}
-    for name, cls in specs:
-        m = synth.load_hashed(cls(), name + ".")
-        if keep_cpu:
-            cpu_sd[name] = {k: v.clone() for k, v in m.state_dict().items()}
-        # text encoder on the f32 kernels, as pipeline.generate runs it (see pipeline.py)
-        models[name] = engine.set_compute_dtype(m.to(device), torch.float32 if name == "clip" else dtype)
-    return models, cpu_sd
-
-
-class Txt2ImgJob:
-    """Everything of generate() that can be prepared ahead, for a fixed batch of prompts/seeds."""
-
-    def __init__(self, models, first_image, batch, denoise_steps, cfg_scale, device, use_graph=True):
-        self.models, self.B = models, batch
-        ids = [synth.synthetic_token_ids(first_image + i) for i in range(batch)]
-        self.pos = torch.tensor(ids, dtype=torch.long, device=device)
-        self.neg = torch.tensor([synth.EMPTY_PROMPT_IDS] * batch, dtype=torch.long, device=device)
-        seeds = [42 + first_image + i for i in range(batch)]
-        ts, coef, noise, lat = pipeline.prepare_latents(seeds, pipeline.DDPMSampler, denoise_steps, (1, 4, 64, 64), device)
-        self.latents0 = lat.float().contiguous()
-        ctx = pipeline.encode_prompts(models["clip"], self.pos, self.neg)
-        self.loop = pipeline.DenoiseLoop(models["diffusion"], ctx, ts, coef, noise, self.latents0, cfg_scale, True, use_graph)
-
-    def step(self):
-        ctx = pipeline.encode_prompts(self.models["clip"], self.pos, self.neg)
-        self.loop.set_context(ctx)
-        self.loop.reset(self.latents0)
-        final = self.loop.run()
-        images = pipeline.decode_to_uint8(self.models["decoder"], final)
-        return distributed.all_gather_images(images)
-
-
-def unet_step_ms(loop, latents0, iters=10):
-    loop.reset(latents0)
-    loop.step()
-    torch.cuda.synchronize()
-    loop.reset(latents0)
-    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    s.record()
-    for _ in range(iters):
-        loop.step()
-    e.record()
-    torch.cuda.synchronize()
-    return s.elapsed_time(e) / iters
-
-
-def roofline_leg(models, args, device):
-    """One eager pass of the same step with HIP-event pairs around every heavy launch."""
-    job = Txt2ImgJob(models, 0, args.batch, args.denoise_steps, 7.5, device, use_graph=False)
-    job.step()                                     # warm (weights already packed)
-    torch.cuda.synchronize()
-    ops.PROFILER = ops.LaunchTimer()
-    try:
-        job.step()
-        summ = ops.PROFILER.summary()
-    finally:
-        ops.PROFILER = None
-    rows = []
-    for kind, v in summ.items():
-        mfma = kind.split("_")[0] in ("conv3x3", "gemm", "attention")
-        dt = "bf16" if "_bf16" in kind else "f32"
-        rate = v["work"] / (v["ms"] * 1e-3) / (1e12 if mfma else 1e9)
-        rows.append({"kernel": kind, "launches": v["launches"], "total_ms": round(v["ms"], 3),
-                     "avg_us": round(1e3 * v["ms"] / v["launches"], 2), "bound": "mfma" if mfma else "hbm",
-                     "achieved": round(rate, 2), "unit": "TFLOP/s" if mfma else "GB/s",
-                     "frac": round(rate / (PEAK[dt] if mfma else PEAK["hbm"]), 4)})
-    rows.sort(key=lambda r: -r["total_ms"])
-    # the roofline object is per kernel SYMBOL (what a rocprofv3 trace shows): split-K variants and all
-    # problem shapes of one template instantiation are one entry
-    by_sym = {}
-    for kind, v in summ.items():
-        e = by_sym.setdefault(kernel_symbol(kind), {"ms": 0.0, "work": 0.0, "launches": 0, "kinds": []})
-        e["ms"] += v["ms"]; e["work"] += v["work"]; e["launches"] += v["launches"]; e["kinds"].append(kind)
-    sym, top = max(by_sym.items(), key=lambda kv: kv[1]["ms"])
-    mfma = top["kinds"][0].split("_")[0] in ("conv3x3", "gemm", "attention")
-    dt = "bf16" if "_bf16" in top["kinds"][0] else "f32"
-    peak = PEAK[dt] if mfma else PEAK["hbm"]
-    rate = top["work"] / (top["ms"] * 1e-3) / (1e12 if mfma else 1e9)
-    roof = {"kernel": sym, "labels": sorted(top["kinds"]), "bound": "mfma" if mfma else "hbm",
-            "achieved": round(rate, 2), "peak": peak, "unit": "TFLOP/s" if mfma else "GB/s", "frac": round(rate / peak, 4),
-            "traffic": pmc_traffic(sym), "launches": top["launches"],
-            "avg_launch_us": round(1e3 * top["ms"] / top["launches"], 2),
-            "algorithmic_work_per_launch": round(top["work"] / top["launches"] / (1e9 if mfma else 1e6), 3),
-            "work_unit": "GFLOP" if mfma else "MB",
-            "note": "dominant kernel symbol of one bench step (most summed time over all its launches): mean algorithmic FLOPs per "
-                    "launch / mean launch duration, HIP events on the launch stream in one extra eager pass; traffic = mean HBM bytes "
-                    "per launch from profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over eager UNet "
-                    "steps, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950), null if not collected"}
-    return roof, rows
+PMC_TRAFFIC_FILES = ("r02_pmc_traffic.json", "r01_pmc_traffic.json")   # newest first
 
 
 def kernel_symbol(kind):
@@ -139,8 +45,8 @@ def kernel_symbol(kind):
         bm, bn = parts[2].split("x")
         conv = "true" if parts[0] == "conv3x3" else "false"
         t = "unsigned short" if parts[1] == "bf16" else "float"
-        wg = {"128x320": "2, 4, 2", "128x160": "2, 2, 2", "256x256": "2, 4, 2"}.get(parts[2])
-        if wg is not None:      # 8-wave / 4-wave LDS-DMA family (gemm2.hip); last argument: 1 = residual-prefetch, 2 = GeGLU-only epilogue
+        wg = {"128x320": "2, 4, 2", "128x160": "2, 2, 2", "256x256": "2, 4, 2", "256x320": "4, 2, 2"}.get(parts[2])
+        if wg is not None:      # LDS-DMA family (gemm2.hip); last argument: 1 = residual-prefetch, 2 = GeGLU-only epilogue
             return f"gemm2_kernel<{t}, {bm}, {bn}, {wg}, {conv}, {1 if 'rp' in parts[3:] else 2 if 'geglu' in parts[3:] else 0}>"
         return f"gemm_kernel<{t}, {bm}, {bn}, {conv}>"
     if parts[0] == "attention":
@@ -148,39 +54,17 @@ def kernel_symbol(kind):
         return f"attn_kernel<{t}, {parts[2][1:]}>"
     return kind
 
-
 def pmc_traffic(symbol):
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    if not os.path.exists(path):
-        return None
-    ent = json.load(open(path)).get(symbol)
-    return None if ent is None else ent["hbm_bytes_per_launch"]
+    for name in PMC_TRAFFIC_FILES:
+        path = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(path):
+            ent = json.load(open(path)).get(symbol)
+            if ent is not None:
+                return ent["hbm_bytes_per_launch"], name
+    return None, None
 
 
-def cpu_baseline_leg(cpu_sd):
-    """CPU oracle (a port of the reference path) on a bounded sample, extrapolated to 1 image."""
-    from oracle import sd_oracle as O
-    threads = torch.get_num_threads()
-    lat = torch.randn(2, 4, 64, 64, generator=torch.Generator().manual_seed(0))
-    toks = torch.tensor([synth.synthetic_token_ids(0), synth.EMPTY_PROMPT_IDS])
-    t0 = time.perf_counter()
-    ctx = O.clip_forward(cpu_sd["clip"], toks)
-    t_clip2 = time.perf_counter() - t0
-    temb = O.get_time_embedding(980)
-    t0 = time.perf_counter()
-    O.diffusion_forward(cpu_sd["diffusion"], lat, ctx, temb)
-    t_unet = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    O.vae_decode(cpu_sd["decoder"], lat[:1])
-    t_dec = time.perf_counter() - t0
-    per_image = 50 * t_unet + t_dec + t_clip2
-    return {"value": round(1.0 / per_image, 6), "unit": "images/s", "cores": threads, "kind": "port",
-            "sample": f"1 UNet step b2@64x64 fp32 ({t_unet:.2f}s) + 1 VAE decode ({t_dec:.2f}s) + 2 CLIP encodes "
-                      f"({t_clip2:.2f}s) on {threads} threads, extrapolated to 50 steps + final decode only",
-            "unet_step_s": round(t_unet, 3), "vae_decode_s": round(t_dec, 3)}
-
-
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
@@ -190,11 +74,205 @@ def main():
     ap.add_argument("--skip-cpu-baseline", action="store_true")
     ap.add_argument("--skip-roofline", action="store_true")
     ap.add_argument("--skip-fp32-latency", action="store_true")
-    args = ap.parse_args()
+    ap.add_argument("--skip-generate-wall", action="store_true")
+    return ap.parse_args()
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a torchrun environment: start the N ranks as fresh child processes
+    (torch.distributed.run, one per GPU) BEFORE this process touches the GPU, relay rank 0's JSON line."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args))
+    run(args)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+def run(args):
+    import torch
+    import sd_amd  # noqa: F401
+    from sd_amd import clip, decoder, diffusion, distributed, engine, ops, pipeline, synth
+
+    def build_models(device, dtype, keep_cpu):
+        torch.set_grad_enabled(False)
+        specs = (("clip", clip.CLIP), ("decoder", decoder.VAE_Decoder), ("diffusion", diffusion.Diffusion))
+        models, cpu_sd = {}, {}
+        for name, cls in specs:
+            m = synth.load_hashed(cls(), name + ".")
+            if keep_cpu:
+                cpu_sd[name] = {k: v.clone() for k, v in m.state_dict().items()}
+            # text encoder on the f32 kernels, as pipeline.generate runs it (see pipeline.py)
+            models[name] = engine.set_compute_dtype(m.to(device), torch.float32 if name == "clip" else dtype)
+        return models, cpu_sd
+
+    class Txt2ImgJob:
+        """Everything of generate() that can be prepared ahead, for a fixed batch of prompts/seeds."""
+
+        def __init__(self, models, first_image, batch, denoise_steps, cfg_scale, device, use_graph=True):
+            self.models, self.B = models, batch
+            ids = [synth.synthetic_token_ids(first_image + i) for i in range(batch)]
+            self.pos = torch.tensor(ids, dtype=torch.long, device=device)
+            self.neg = torch.tensor([synth.EMPTY_PROMPT_IDS] * batch, dtype=torch.long, device=device)
+            seeds = [42 + first_image + i for i in range(batch)]
+            ts, coef, noise, lat = pipeline.prepare_latents(seeds, pipeline.DDPMSampler, denoise_steps, (1, 4, 64, 64), device)
+            self.latents0 = lat.float().contiguous()
+            ctx = pipeline.encode_prompts(models["clip"], self.pos, self.neg)
+            self.loop = pipeline.DenoiseLoop(models["diffusion"], ctx, ts, coef, noise, self.latents0, cfg_scale, True, use_graph)
+
+        def step(self):
+            ctx = pipeline.encode_prompts(self.models["clip"], self.pos, self.neg)
+            self.loop.set_context(ctx)
+            self.loop.reset(self.latents0)
+            final = self.loop.run()
+            images = pipeline.decode_to_uint8(self.models["decoder"], final)
+            return distributed.all_gather_images(images)
+
+    def unet_step_ms(loop, latents0, iters=20, warm=3):
+        """one captured Diffusion forward + CFG + step; median of >= 20 after 3 warm-ups, HIP events."""
+        iters = max(1, min(iters, loop.n_steps - warm)) if loop.n_steps > warm else 1
+        warm = min(warm, max(0, loop.n_steps - iters))
+        loop.reset(latents0)
+        for _ in range(warm):
+            loop.step()
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(iters + 1)]
+        evs[0].record()
+        for i in range(iters):
+            loop.step()
+            evs[i + 1].record()
+        torch.cuda.synchronize()
+        times = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(iters))
+        loop.reset(latents0)
+        return times[len(times) // 2]
+
+    def roofline_leg(models, device):
+        """One eager pass of the same step with HIP-event pairs around every heavy launch."""
+        job = Txt2ImgJob(models, 0, args.batch, args.denoise_steps, 7.5, device, use_graph=False)
+        job.step()                                     # warm (weights already packed)
+        torch.cuda.synchronize()
+        ops.PROFILER = ops.LaunchTimer()
+        try:
+            job.step()
+            summ = ops.PROFILER.summary()
+        finally:
+            ops.PROFILER = None
+        is_mfma = lambda kind: kind.split("_")[0] in ("conv3x3", "gemm", "attention")
+        rows = []
+        for kind, v in summ.items():
+            mfma = is_mfma(kind)
+            dt = "bf16" if "_bf16" in kind else "f32"
+            rate = v["work"] / (v["ms"] * 1e-3) / (1e12 if mfma else 1e9)
+            rows.append({"kernel": kind, "launches": v["launches"], "total_ms": round(v["ms"], 3),
+                         "avg_us": round(1e3 * v["ms"] / v["launches"], 2), "bound": "mfma" if mfma else "hbm",
+                         "achieved": round(rate, 2), "unit": "TFLOP/s" if mfma else "GB/s",
+                         "frac": round(rate / (PEAK[dt] if mfma else PEAK["hbm"]), 4)})
+        rows.sort(key=lambda r: -r["total_ms"])
+        # the roofline object is per kernel SYMBOL (what a rocprofv3 trace shows): split-K variants and all
+        # problem shapes of one template instantiation are one entry
+        by_sym = {}
+        for kind, v in summ.items():
+            e = by_sym.setdefault(kernel_symbol(kind), {"ms": 0.0, "work": 0.0, "bytes": 0.0, "launches": 0, "kinds": []})
+            e["ms"] += v["ms"]; e["work"] += v["work"]; e["bytes"] += v["bytes"]; e["launches"] += v["launches"]; e["kinds"].append(kind)
+        sym, top = max(by_sym.items(), key=lambda kv: kv[1]["ms"])
+        mfma = is_mfma(top["kinds"][0])
+        dt = "bf16" if "_bf16" in top["kinds"][0] else "f32"
+        peak = PEAK[dt] if mfma else PEAK["hbm"]
+        rate = top["work"] / (top["ms"] * 1e-3) / (1e12 if mfma else 1e9)
+        traffic, traffic_src = pmc_traffic(sym)
+        roof = {"kernel": sym, "labels": sorted(top["kinds"]), "bound": "mfma" if mfma else "hbm",
+                "achieved": round(rate, 2), "peak": peak, "unit": "TFLOP/s" if mfma else "GB/s", "frac": round(rate / peak, 4),
+                "traffic": traffic, "traffic_source": traffic_src, "launches": top["launches"],
+                "avg_launch_us": round(1e3 * top["ms"] / top["launches"], 2),
+                "algorithmic_work_per_launch": round(top["work"] / top["launches"] / (1e9 if mfma else 1e6), 3),
+                "work_unit": "GFLOP" if mfma else "MB",
+                "algorithmic_bytes_per_launch": round(top["bytes"] / top["launches"]),
+                "note": "dominant kernel symbol of one bench step (most summed time over all its launches): mean algorithmic FLOPs "
+                        "per launch / mean launch duration (HIP events on the launch stream, one extra eager pass; a split-K launch "
+                        "includes its reduce kernel).  FLOPs are the reference op's 2*M*N*K (SURVEY.md §8d): the hi|lo operand "
+                        "doubling and the 4/9-MAC upsample form earn no credit.  algorithmic_bytes = operands + weights + result "
+                        "(+ residual), each once.  traffic = mean fabric bytes per launch from profiles/<traffic_source> (rocprofv3 "
+                        "--pmc FETCH_SIZE / WRITE_SIZE passes over eager UNet steps, FETCH_SIZE doubled as MI355X_MICROARCH.md "
+                        "prescribes for gfx950), null if not collected for this symbol"}
+        return roof, rows
+
+    def cpu_model():
+        try:
+            for line in open("/proc/cpuinfo"):
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+        except OSError:
+            pass
+        return "unknown"
+
+    def cpu_baseline_leg(cpu_sd):
+        """BASELINE config 1 (txt2img b1, 50-step DDPM, CFG 7.5, fp32, CPU) on the CPU oracle, bounded: the first 2 of
+        the 50 UNet steps (UNet batch 2, sampler step included), 1 VAE decode, the 2 CLIP encodes -- each stage timed,
+        then summed to the full run, once as this framework runs it (final decode only) and once as the reference runs
+        it (preview decode after every step, pipeline.py:156-164)."""
+        from oracle import sd_oracle as O
+        threads = torch.get_num_threads()
+        toks = torch.tensor([synth.synthetic_token_ids(0), synth.EMPTY_PROMPT_IDS])
+        t0 = time.perf_counter()
+        ctx = O.clip_forward(cpu_sd["clip"], toks)
+        t_clip2 = time.perf_counter() - t0
+        samp = O.DDPMSampler(torch.Generator().manual_seed(42))
+        samp.set_steps(50)
+        lat = torch.randn((1, 4, 64, 64), generator=samp.generator)
+        t_unet = []
+        for t in samp.timesteps[:2]:
+            t0 = time.perf_counter()
+            out = O.diffusion_forward(cpu_sd["diffusion"], lat.repeat(2, 1, 1, 1), ctx, O.get_time_embedding(int(t)))
+            eps = 7.5 * (out[0:1] - out[1:2]) + out[1:2]
+            lat = samp.step(int(t), lat, eps)
+            t_unet.append(time.perf_counter() - t0)
+        t_unet = sum(t_unet) / len(t_unet)
+        t0 = time.perf_counter()
+        O.vae_decode(cpu_sd["decoder"], lat)
+        t_dec = time.perf_counter() - t0
+        per_image = 50 * t_unet + t_dec + t_clip2
+        per_image_preview = 50 * (t_unet + t_dec) + t_clip2
+        return {"value": round(1.0 / per_image, 6), "unit": "images/s", "cores": threads, "kind": "port",
+                "cpu_model": cpu_model(), "host_cpus": os.cpu_count(),
+                "value_with_preview_decode": round(1.0 / per_image_preview, 6),
+                "sample": f"BASELINE config 1 bounded: steps 1-2 of 50 (UNet b2@64x64 fp32 + CFG + DDPM step, mean {t_unet:.2f}s) + 1 VAE "
+                          f"decode ({t_dec:.2f}s) + 2 CLIP encodes ({t_clip2:.2f}s) on {threads} threads; value = 1 / (50 steps + final "
+                          f"decode + CLIP) = {per_image:.0f}s per image; value_with_preview_decode = the reference's loop with its "
+                          f"per-step preview decode = {per_image_preview:.0f}s per image",
+                "unet_step_s": round(t_unet, 3), "vae_decode_s": round(t_dec, 3), "clip2_s": round(t_clip2, 3)}
+
+    def generate_wall_leg(models, device, world, rank):
+        """wall(pipeline.generate(...)) for the same batch, as SURVEY.md §8d defines images/sec: tokenise, CLIP, host
+        noise draw (CPU mt19937, the reference's stream) + upload, 50 steps, decode, uint8, device->host copy of the
+        images.  Graph capture happens in the first (untimed) call and is re-used (pipeline._denoise_loop)."""
+        tok = synth.SyntheticTokenizer()
+        prompts = [f"synthetic:{rank * args.batch + i}" for i in range(args.batch)]
+        kw = dict(models=models, seed=42 + rank * args.batch, device=str(device), sampler="ddpm", steps=args.denoise_steps,
+                  cfg_scale=7.5, tokenizer=tok, compute_dtype=torch.bfloat16)
+        pipeline.generate(prompts, "", **kw)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n = 2
+        for _ in range(n):
+            imgs = pipeline.generate(prompts, "", **kw)
+        dt = (time.perf_counter() - t0) / n
+        assert imgs.shape == (args.batch, 512, 512, 3)
+        pipeline.clear_loop_cache()
+        return dt
 
     rank, world, local = distributed.init_from_env()
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     dtype = torch.bfloat16
@@ -213,6 +291,9 @@ def main():
     elapsed = distributed.max_over_ranks(time.perf_counter() - t0, device)
     assert out.shape[0] == world * args.batch and out.dtype == torch.uint8
 
+    gen_wall = None
+    if not args.skip_generate_wall:
+        gen_wall = distributed.max_over_ranks(generate_wall_leg(models, device, world, rank), device)
     if rank != 0:
         return
     ms_per_step = 1e3 * elapsed / args.steps
@@ -229,9 +310,16 @@ def main():
         "tflops_effective": round(value * GFLOP_PER_IMAGE / 1e3, 1),
         "frac_of_bf16_mfma_peak": round(value * GFLOP_PER_IMAGE / 1e3 / (PEAK["bf16"] * world), 4),
     }
-    extra = {"unet_step_ms_bf16": round(unet_step_ms(job.loop, job.latents0), 3), "unet_batch_bf16": 2 * args.batch}
+    extra = {"unet_step_ms_bf16": round(unet_step_ms(job.loop, job.latents0), 3), "unet_batch_bf16": 2 * args.batch,
+             "unet_step_latency_method": "median of 20 graph replays after 3 warm-ups, HIP events per replay"}
+    if gen_wall is not None:
+        extra["generate_wall_s"] = round(gen_wall, 4)
+        extra["generate_wall_images_per_s"] = round(world * args.batch / gen_wall, 4)
+        extra["generate_wall_note"] = ("wall(pipeline.generate(list of prompts)) per call, max over ranks, captured graph re-used: "
+                                       "includes tokenising, the host noise draw (50 x B x 16384 normals from the CPU generator) and "
+                                       "its upload, CLIP, 50 steps, VAE decode, uint8 and the device->host image copy; no all-gather")
     if not args.skip_roofline:
-        roof, rows = roofline_leg(models, args, device)
+        roof, rows = roofline_leg(models, device)
         result["roofline"] = roof
         extra["kernel_breakdown"] = rows[:12]
         # north_star: achieved HBM GB/s of the fused norm and sampler kernels against the 8 TB/s peak

@@ -44,17 +44,21 @@ int sdamd_device_count(void); /* >=0, or -hipError when no driver/GPU */
  * cx_on_eps = 0 is the DDPM step (ddpm.py:59-85), 1 the deterministic DDIM step
  * (sampler/ddim.py:50-72: c0 = sqrt(abar_prev), cx = sqrt(1-abar_prev), no noise).
  * The schedule index is *step_ptr (device int, for graph replay) or `step` when step_ptr is
- * null. Bit-exact vs torch CPU. */
+ * null; coef (and noise) have n_steps rows: a host `step` outside [0, n_steps) is an error, a
+ * device index outside it makes the launch a no-op (latents untouched) instead of reading past
+ * the tables.  A null `noise` is read as "no noise" whatever has_noise says: the caller checks its
+ * table (pipeline.DenoiseLoop does).  Bit-exact vs torch CPU. */
 int sdamd_cfg_ddpm_step(float* latents, const float* eps, const float* noise, const float* coef,
-                        const int* step_ptr, int step, float cfg_scale, int do_cfg, int B, int n,
-                        void* stream);
+                        const int* step_ptr, int step, int n_steps, float cfg_scale, int do_cfg,
+                        int B, int n, void* stream);
 int sdamd_counter_add(int* counter, int delta, void* stream);
 /* sampler/ddpm.py:91-111: out = sqrt_abar*x + sqrt_one_minus_abar*noise */
 int sdamd_add_noise(float* out, const float* x, const float* noise, float sqrt_abar,
                     float sqrt_one_minus_abar, long long total, void* stream);
-/* dst[0:width] = table[idx][0:width], idx = *step_ptr or step (per-step time-bias rows) */
-int sdamd_gather_row(float* dst, const float* table, const int* step_ptr, int step, int width,
-                     void* stream);
+/* dst[0:width] = table[idx][0:width], idx = *step_ptr or step (per-step time-bias rows); table has
+ * `rows` rows, an index outside them is an error (host step) or leaves dst untouched (device index) */
+int sdamd_gather_row(float* dst, const float* table, const int* step_ptr, int step, int rows,
+                     int width, void* stream);
 
 /* ---- normalisation: nn.GroupNorm(32,C)(+F.silu) diffusion.py:26-28,38-40,93,292-294,
  * decoder.py:25-30,49,118-120; x,y NHWC [B][HW][C]; ws >= sdamd_groupnorm_ws_bytes(B).
@@ -148,11 +152,13 @@ int sdamd_set_gemm_impl(int impl);
 int sdamd_conv3x3(const void* x, const void* w, void* y, const float* bias, const void* residual,
                   int B, int H, int W, int Cin, int Cout, int stride, int pad_mode, int upsample,
                   int act, int dtype, int out_f32, void* ws, size_t ws_bytes, void* stream);
-/* first convs (diffusion.py:196, decoder.py:78, encoder.py:10): x NCHW f32, Cin 3|4,
- * w [ky][kx][Cin][Cout] f32 -> y NHWC dtype */
+/* first convs (diffusion.py:196, decoder.py:78, encoder.py:10): x NCHW f32 [B], Cin 3|4,
+ * w [ky][kx][Cin][Cout] f32 -> y NHWC dtype [copies*B]: sample n is written `copies` times, at
+ * n, n+B, ... (copies = 2: the UNet input under classifier-free guidance is the same latents
+ * twice, pipeline.py:147 `latents.repeat(2,1,1,1)`, so the conv runs once) */
 int sdamd_conv3x3_cin_small(const float* x_nchw, const float* w_tap_ci_co, const float* bias,
-                            void* y_nhwc, int B, int H, int W, int Cin, int Cout, int dtype,
-                            void* stream);
+                            void* y_nhwc, int B, int H, int W, int Cin, int Cout, int copies,
+                            int dtype, void* stream);
 /* last convs (diffusion.py:287, decoder.py:123, encoder.py:54): x NHWC dtype, Cout 3|4|8,
  * w [tap][Cin/V][Cout][V] dtype (V = 16 bytes of dtype) -> y NCHW f32 */
 int sdamd_conv3x3_cout_small(const void* x_nhwc, const void* w_packed, const float* bias,

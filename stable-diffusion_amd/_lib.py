@@ -16,10 +16,10 @@ SIGNATURES = {
     "sdamd_last_error": (ctypes.c_char_p, []),
     "sdamd_abi_version": (_i, []),
     "sdamd_device_count": (_i, []),
-    "sdamd_cfg_ddpm_step": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _f, _i, _i, _i, _vp]),
+    "sdamd_cfg_ddpm_step": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _i, _i, _i, _vp]),
     "sdamd_counter_add": (_i, [_vp, _i, _vp]),
     "sdamd_add_noise": (_i, [_vp, _vp, _vp, _f, _f, _ll, _vp]),
-    "sdamd_gather_row": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
+    "sdamd_gather_row": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     "sdamd_groupnorm_ws_bytes": (_sz, [_i]),
     "sdamd_groupnorm_nhwc": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _i, _i, _vp]),
     "sdamd_groupnorm_nhwc_cat": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _f, _i, _i, _i, _vp]),
@@ -45,7 +45,7 @@ SIGNATURES = {
     "sdamd_set_gemm_impl": (_i, [_i]),
     "sdamd_gemm_supports_act": (_i, [_i, _i, _i]),
     "sdamd_conv3x3": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
-    "sdamd_conv3x3_cin_small": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "sdamd_conv3x3_cin_small": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "sdamd_conv3x3_cout_small": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "sdamd_attention": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _ll, _i, _ll, _i, _ll, _i, _ll, _i, _i, _i, _vp]),
 }

@@ -369,11 +369,9 @@ template <typename T, int D>
 static int launch_attn(const AttnArgs& a, int B, hipStream_t st) {
   dim3 grid((a.Sq + 127) / 128, B * a.H);
   constexpr int lds = 2 * AttnCfg<T, D>::STAGE;
-  static bool attr_set = false;
-  if (!attr_set && lds > 48 * 1024) {
-    (void)hipFuncSetAttribute((const void*)attn_kernel<T, D>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    attr_set = true;
-  }
+  static std::atomic<unsigned long long> lds_ok{0};
+  if (lds > 48 * 1024 && sd_lds_opt_in(lds_ok, (const void*)attn_kernel<T, D>, lds) != hipSuccess)
+    return sdamd_set_error(2, "attention: cannot reserve %d bytes of LDS", lds);
   attn_kernel<T, D><<<grid, 256, lds, st>>>(a);
   SD_LAUNCH_CHECK("attention");
   return 0;

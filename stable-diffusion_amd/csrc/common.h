@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 
 #define SDAMD_F32 0
 #define SDAMD_BF16 1
@@ -123,3 +124,17 @@ int sdamd_set_error(int code, const char* fmt, ...);
 #define SD_CHECK(cond, ...) do { if (!(cond)) return sdamd_set_error(1, __VA_ARGS__); } while (0)
 #define SD_LAUNCH_CHECK(name) do { hipError_t e_ = hipGetLastError(); \
   if (e_ != hipSuccess) return sdamd_set_error(2, "%s: launch failed: %s", name, hipGetErrorString(e_)); } while (0)
+
+// Opt a kernel in to `bytes` of dynamic LDS, once per (kernel instantiation, device): the attribute applies to the
+// CURRENT device only, so the done-flag is a per-device bit mask (one static mask per launcher instantiation).
+// Setting it twice from two host threads is harmless.
+static inline hipError_t sd_lds_opt_in(std::atomic<unsigned long long>& done, const void* fn, int bytes) {
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (done.load(std::memory_order_acquire) & bit) return hipSuccess;
+  e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e == hipSuccess) done.fetch_or(bit, std::memory_order_release);
+  return e;
+}

@@ -17,12 +17,13 @@
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void cfg_ddpm_step_kernel(float* __restrict__ lat, const float* __restrict__ eps,
                                                             const float* __restrict__ noise, const float* __restrict__ coef,
-                                                            const int* __restrict__ step_ptr, int step, float cfg_scale,
-                                                            int do_cfg, int B, int n) {
+                                                            const int* __restrict__ step_ptr, int step, int n_steps,
+                                                            float cfg_scale, int do_cfg, int B, int n) {
   const int s = step_ptr ? *step_ptr : step;
+  if ((unsigned)s >= (unsigned)n_steps) return;   // replay past the schedule: touch nothing (coef / noise rows end at n_steps)
   const float* c = coef + (size_t)s * 8;
   const float sa = c[0], sb = c[1], c0 = c[2], cx = c[3], sigma = c[4];
-  const bool has_noise = c[5] != 0.0f, cx_on_eps = c[6] != 0.0f;
+  const bool has_noise = c[5] != 0.0f && noise != nullptr, cx_on_eps = c[6] != 0.0f;
   const size_t total = (size_t)B * n;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
     float e;
@@ -52,8 +53,9 @@ __global__ __launch_bounds__(256) void add_noise_kernel(float* __restrict__ out,
 // dst[r][:] = table[idx][:] for idx = *step_ptr (or step): picks this step's row of a per-step
 // table (time-projection biases) so graph replays read fixed addresses.
 __global__ __launch_bounds__(256) void gather_row_kernel(float* __restrict__ dst, const float* __restrict__ table,
-                                                         const int* __restrict__ step_ptr, int step, int width) {
+                                                         const int* __restrict__ step_ptr, int step, int rows, int width) {
   const int s = step_ptr ? *step_ptr : step;
+  if ((unsigned)s >= (unsigned)rows) return;      // index past the table: leave dst as it is
   for (int i = blockIdx.x * 256 + threadIdx.x; i < width; i += gridDim.x * 256) dst[i] = table[(size_t)s * width + i];
 }
 
@@ -285,12 +287,13 @@ static inline int grid_for(size_t work_items) {
 }
 
 extern "C" int sdamd_cfg_ddpm_step(float* latents, const float* eps, const float* noise, const float* coef,
-                                   const int* step_ptr, int step, float cfg_scale, int do_cfg, int B, int n,
-                                   void* stream) {
+                                   const int* step_ptr, int step, int n_steps, float cfg_scale, int do_cfg, int B,
+                                   int n, void* stream) {
   SD_CHECK(B > 0 && n > 0, "cfg_ddpm_step: empty input B=%d n=%d", B, n);
   SD_CHECK(latents && eps && coef, "cfg_ddpm_step: null pointer");
+  SD_CHECK(n_steps > 0 && (step_ptr || (step >= 0 && step < n_steps)), "cfg_ddpm_step: step %d outside the %d-row schedule", step, n_steps);
   cfg_ddpm_step_kernel<<<grid_for((size_t)B * n), 256, 0, (hipStream_t)stream>>>(latents, eps, noise, coef, step_ptr, step,
-                                                                               cfg_scale, do_cfg, B, n);
+                                                                               n_steps, cfg_scale, do_cfg, B, n);
   SD_LAUNCH_CHECK("cfg_ddpm_step");
   return 0;
 }
@@ -310,9 +313,11 @@ extern "C" int sdamd_add_noise(float* out, const float* x, const float* noise, f
   return 0;
 }
 
-extern "C" int sdamd_gather_row(float* dst, const float* table, const int* step_ptr, int step, int width, void* stream) {
-  SD_CHECK(width > 0, "gather_row: empty row");
-  gather_row_kernel<<<grid_for((size_t)width), 256, 0, (hipStream_t)stream>>>(dst, table, step_ptr, step, width);
+extern "C" int sdamd_gather_row(float* dst, const float* table, const int* step_ptr, int step, int rows, int width,
+                                void* stream) {
+  SD_CHECK(width > 0 && rows > 0, "gather_row: empty table");
+  SD_CHECK(step_ptr || (step >= 0 && step < rows), "gather_row: row %d outside the %d-row table", step, rows);
+  gather_row_kernel<<<grid_for((size_t)width), 256, 0, (hipStream_t)stream>>>(dst, table, step_ptr, step, rows, width);
   SD_LAUNCH_CHECK("gather_row");
   return 0;
 }

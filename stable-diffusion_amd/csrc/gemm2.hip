@@ -553,12 +553,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
 template <typename T, int BM, int BN, int WGM, int WGN, int STAGES, bool CONV, int EPI>
 static int launch2_epi(GemmArgs& a, int batch, hipStream_t st) {
   constexpr int lds = STAGES * (BM + BN) * 128;
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)gemm2_kernel<T, BM, BN, WGM, WGN, STAGES, CONV, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
-      return sdamd_set_error(2, "gemm2: cannot reserve %d bytes of LDS", lds);
-    attr_set = true;
-  }
+  static std::atomic<unsigned long long> lds_ok{0};
+  if (sd_lds_opt_in(lds_ok, (const void*)gemm2_kernel<T, BM, BN, WGM, WGN, STAGES, CONV, EPI>, lds) != hipSuccess)
+    return sdamd_set_error(2, "gemm2: cannot reserve %d bytes of LDS", lds);
   dim3 grid(a.tiles_m * a.tiles_n, batch, a.splits);
   gemm2_kernel<T, BM, BN, WGM, WGN, STAGES, CONV, EPI><<<grid, WGM * WGN * 64, lds, st>>>(a);
   SD_LAUNCH_CHECK("gemm2");
@@ -615,10 +612,10 @@ int gemm2_choose_tile(int M, int N, int K, int batch, int mode, size_t ws_bytes,
   }
   extern int g_gemm_debug;
   if (g_gemm_debug >= 32) {   // experiment: forced tile / split (debug = 32 + 8*tile + splits)
-    static const int tiles[4] = {128160, 128320, 256256, 128128};
+    static const int tiles[8] = {128160, 128320, 256256, 128128, 256320, 0, 0, 0};
     const int s = (g_gemm_debug - 32) & 7;
     if (s >= 1 && s <= max_splits() && s <= nk) *splits = s;
-    return tiles[((g_gemm_debug - 32) >> 3) & 3];
+    return tiles[((g_gemm_debug - 32) >> 3) & 7];
   }
   // bf16: the 4-wave 128x160 tile (two co-resident workgroups per CU overlap each other's prologue and
   // epilogue) beats the 8-wave 128x320 one by 3-9 % once it fills two rounds (>= 512 workgroups), except on
@@ -674,6 +671,9 @@ static int launch_gemm2_t(GemmArgs& a, int batch, bool conv, int mode, hipStream
     case 128160: return conv ? launch2<T, 128, 160, 2, 2, 2, true>(a, batch, st) : launch2<T, 128, 160, 2, 2, 2, false>(a, batch, st);
     case 128320: return conv ? launch2<T, 128, 320, 2, 4, 2, true>(a, batch, st) : launch2<T, 128, 320, 2, 4, 2, false>(a, batch, st);
     case 256256: return conv ? launch2<T, 256, 256, 2, 4, 2, true>(a, batch, st) : launch2<T, 256, 256, 2, 4, 2, false>(a, batch, st);
+    case 256320:
+      if constexpr (sizeof(T) == 2) return conv ? launch2<T, 256, 320, 4, 2, 2, true>(a, batch, st) : launch2<T, 256, 320, 4, 2, 2, false>(a, batch, st);
+      else return -1;
     default: a.splits = 1; return -1;
   }
 }

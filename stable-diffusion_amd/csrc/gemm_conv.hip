@@ -231,7 +231,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
 template <typename T, int CIN>
 __global__ __launch_bounds__(256) void conv3x3_cin_small_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                                 const float* __restrict__ bias, T* __restrict__ y, int B,
-                                                                int H, int Wd, int Cout) {
+                                                                int H, int Wd, int Cout, int copies) {
   const int q = Cout / 4;
   const size_t total = (size_t)B * H * Wd * q;
   for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
@@ -258,7 +258,9 @@ __global__ __launch_bounds__(256) void conv3x3_cin_small_kernel(const float* __r
       }
     }
     float o[4] = {acc[0], acc[1], acc[2], acc[3]};
-    store_n<T, 4>(y + pix * Cout + cq * 4, o);   // one 16-byte (f32) / 8-byte (bf16) store
+    // one 16-byte (f32) / 8-byte (bf16) store per copy: copy c of sample n is output sample n + c*B (the UNet input
+    // under classifier-free guidance is the same latents twice, pipeline.py:147)
+    for (int c = 0; c < copies; ++c) store_n<T, 4>(y + ((size_t)c * B * H * Wd + pix) * Cout + cq * 4, o);
   }
 }
 
@@ -357,11 +359,9 @@ static int launch_gemm(GemmArgs& a, int batch, hipStream_t st) {
   a.tiles_m = (a.M + BM - 1) / BM;
   a.tiles_n = (a.N + BN - 1) / BN;
   const int lds = 2 * (BM + BN) * 128;
-  static bool attr_set = false;
-  if (!attr_set && lds > 48 * 1024) {
-    (void)hipFuncSetAttribute((const void*)gemm_kernel<T, BM, BN, CONV>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    attr_set = true;
-  }
+  static std::atomic<unsigned long long> lds_ok{0};
+  if (lds > 48 * 1024 && sd_lds_opt_in(lds_ok, (const void*)gemm_kernel<T, BM, BN, CONV>, lds) != hipSuccess)
+    return sdamd_set_error(2, "gemm: cannot reserve %d bytes of LDS", lds);
   // split-K for the parallelism-starved shapes (fp32 UNet at batch 2: M = 128 .. 2048 with K up to
   // 23040 leaves most CUs idle): aim at >= 512 workgroups with up to 16 splits (8 -> 16 on the 8x8-level convs of the
   // fp32 UNet at batch 2: -7...-10 % in situ), keep >= 8 K-tiles per split
@@ -545,13 +545,13 @@ extern "C" int sdamd_conv3x3(const void* x, const void* w, void* y, const float*
 }
 
 extern "C" int sdamd_conv3x3_cin_small(const float* x_nchw, const float* w_tap_ci_co, const float* bias, void* y_nhwc, int B,
-                                       int H, int Wd, int Cin, int Cout, int dtype, void* stream) {
+                                       int H, int Wd, int Cin, int Cout, int copies, int dtype, void* stream) {
   SD_CHECK(Cin == 3 || Cin == 4, "conv3x3_cin_small: Cin=%d (3 or 4)", Cin);
-  SD_CHECK(Cout % 4 == 0 && B > 0 && H > 0 && Wd > 0, "conv3x3_cin_small: bad shape");
+  SD_CHECK(Cout % 4 == 0 && B > 0 && H > 0 && Wd > 0 && copies >= 1, "conv3x3_cin_small: bad shape");
   hipStream_t st = (hipStream_t)stream;
   size_t total = (size_t)B * H * Wd * (Cout / 4);
   int g = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
-#define CS(TT, CI) conv3x3_cin_small_kernel<TT, CI><<<g, 256, 0, st>>>(x_nchw, w_tap_ci_co, bias, (TT*)y_nhwc, B, H, Wd, Cout)
+#define CS(TT, CI) conv3x3_cin_small_kernel<TT, CI><<<g, 256, 0, st>>>(x_nchw, w_tap_ci_co, bias, (TT*)y_nhwc, B, H, Wd, Cout, copies)
   if (dtype == SDAMD_BF16) { if (Cin == 3) CS(bf16_t, 3); else CS(bf16_t, 4); }
   else { if (Cin == 3) CS(float, 3); else CS(float, 4); }
 #undef CS

@@ -136,11 +136,31 @@ class TimeEmbedding(engine.HipModule):
         return ops.gemm(h, engine.f32(self.linear_2.weight), engine.f32(self.linear_2.bias))
 
 
-class SwitchSequential(nn.Sequential):
-    """Container only: the stage's members are driven by ``UNET.run``."""
+class SwitchSequential(nn.Sequential, engine.HipModule):
+    """diffusion.py:172-185: dispatches each member by type.  ``UNET.run`` drives the members itself (NHWC, hoisted
+    prompt / time state); ``forward`` keeps the reference's behaviour for a caller that runs one stage directly:
+    NCHW tensors in and out, every member through its own reference-signature ``forward``."""
 
-    def forward(self, x, prompt, time):  # pragma: no cover - kept for API parity (diffusion.py:172-185)
-        raise RuntimeError("SwitchSequential is executed through UNET.forward")
+    def forward(self, x, prompt, time):
+        for layer in self:
+            if isinstance(layer, UNET_AttentionBlock):
+                x = layer(x, prompt)
+            elif isinstance(layer, UNET_ResidualBlock):
+                x = layer(x, time)
+            elif isinstance(layer, Upsample):
+                x = layer(x)
+            else:   # bare nn.Conv2d (stem, stride-2 downsampling): parameters only, executed on the HIP kernels
+                x = _run_plain_conv(layer, x, self.compute_dtype)
+        return x
+
+
+def _run_plain_conv(conv, x, compute_dtype):
+    """A stage's bare nn.Conv2d on NCHW input, as UNET.run executes it (first conv: Cin = 4; else a trunk conv)."""
+    x = x.float().contiguous()
+    trunk = torch.float32     # UNet trunk tensors are f32 in both modes (f32_trunk)
+    if conv.in_channels <= 4:
+        return ops.nhwc_to_nchw(ops.conv3x3_cin_small(x, engine.conv3x3_cin_small_w(conv), engine.f32(conv.bias), trunk))
+    return ops.nhwc_to_nchw(engine.conv3x3_trunk(ops.nchw_to_nhwc(x, trunk), conv, compute_dtype, stride=conv.stride[0]))
 
 
 def _res(cin, cout):
@@ -208,15 +228,16 @@ class UNET(engine.HipModule):
             o += c
         return out
 
-    def run(self, x_nchw, kv, tbias):
-        """x_nchw f32 [B,4,h,w] -> NHWC [B,h,w,320] in the trunk dtype."""
+    def run(self, x_nchw, kv, tbias, copies=1):
+        """x_nchw f32 [B,4,h,w] -> NHWC [copies*B,h,w,320] in the trunk dtype.  ``copies=2``: the UNet batch is the
+        same latents twice (classifier-free guidance, pipeline.py:147); the first conv runs once and writes both."""
         dt = self.trunk_dtype
         skips = []
         x = None
         for i, stage in enumerate(self.encoders):
             if i == 0:
                 c = stage[0]
-                x = ops.conv3x3_cin_small(x_nchw, engine.conv3x3_cin_small_w(c), engine.f32(c.bias), dt)
+                x = ops.conv3x3_cin_small(x_nchw, engine.conv3x3_cin_small_w(c), engine.f32(c.bias), dt, copies)
             else:
                 x = self._stage(stage, x, kv, tbias)
             skips.append(x)
@@ -274,9 +295,9 @@ class Diffusion(engine.HipModule):
         self.unet = UNET(attention_type=attention_type)
         self.final = UNET_Output_Layer(320, 4)
 
-    def run(self, latent, kv, tbias):
-        """latent NCHW f32 [B,4,h,w] -> eps NCHW f32 [B,4,h,w] with hoisted prompt/time state."""
-        return self.final.run(self.unet.run(latent, kv, tbias))
+    def run(self, latent, kv, tbias, copies=1):
+        """latent NCHW f32 [B,4,h,w] -> eps NCHW f32 [copies*B,4,h,w] with hoisted prompt/time state."""
+        return self.final.run(self.unet.run(latent, kv, tbias, copies))
 
     def forward(self, latent, prompt, time):
         """latent [B,4,h,w], prompt [B,77,768], time [1,320] -> [B,4,h,w] f32 (diffusion.py:309-324)."""

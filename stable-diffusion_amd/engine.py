@@ -142,7 +142,7 @@ def conv1x1_presplit(xs, conv, residual):
     """conv1x1 of an operand that already is the hi|lo pair [..., 2C] (see conv1x1): f32 residual, f32 result."""
     w2 = packed(conv.weight, "c1x2", torch.bfloat16,
                 lambda w: w.reshape(w.shape[0], w.shape[1]).to(torch.bfloat16).repeat(1, 2).contiguous())
-    return ops.gemm(xs, w2, bias_of(conv), residual, ops.ACT_NONE, True)
+    return ops.gemm(xs, w2, bias_of(conv), residual, ops.ACT_NONE, True, flops_k=conv.in_channels)
 
 
 def conv1x1(x, conv, residual=None, out_dtype=None, compute_dtype=None, x2=None):
@@ -153,7 +153,7 @@ def conv1x1(x, conv, residual=None, out_dtype=None, compute_dtype=None, x2=None)
         w2 = packed(conv.weight, "c1x2", torch.bfloat16,
                     lambda w: w.reshape(w.shape[0], w.shape[1]).to(torch.bfloat16).repeat(1, 2).contiguous())
         xs = ops.split_hilo(x, x2)
-        return ops.gemm(xs, w2, bias_of(conv), residual, ops.ACT_NONE, _out_f32(xs, residual, out_dtype))
+        return ops.gemm(xs, w2, bias_of(conv), residual, ops.ACT_NONE, _out_f32(xs, residual, out_dtype), flops_k=conv.in_channels)
     assert x2 is None
     return ops.gemm(x, conv1x1_w(conv, x.dtype), bias_of(conv), residual, ops.ACT_NONE, _out_f32(x, residual, out_dtype))
 
@@ -195,10 +195,10 @@ def conv3x3_trunk(x, conv, compute_dtype, stride=1, upsample=False):
         if upsample and ops.gemm_supports_act(ops.ACT_GEGLU, torch.bfloat16, 256) and \
                 (conv.out_channels % 160 == 0 or conv.out_channels % 256 == 0):   # an 8-wave tile divides Cout
             return ops.conv3x3(ops.split_hilo(x), conv3x3_up_phase_w(conv, torch.bfloat16, 2), bias_of(conv), None, 1, 0, 2,
-                               out_f32=True)
+                               out_f32=True, flops_cin=conv.in_channels)
         w2 = packed(conv.weight, "c3x2", torch.bfloat16,
                     lambda w: w.permute(0, 2, 3, 1).to(torch.bfloat16).repeat(1, 1, 1, 2).reshape(w.shape[0], -1).contiguous())
-        return ops.conv3x3(ops.split_hilo(x), w2, bias_of(conv), None, stride, 0, upsample, out_f32=True)
+        return ops.conv3x3(ops.split_hilo(x), w2, bias_of(conv), None, stride, 0, upsample, out_f32=True, flops_cin=conv.in_channels)
     if upsample and stride == 1 and ops.gemm_supports_act(ops.ACT_GEGLU, torch.bfloat16, 256) and \
             (conv.out_channels % 160 == 0 or conv.out_channels % 256 == 0) and x.shape[0] * x.shape[1] * x.shape[2] >= 256:
         # phase form, as conv3x3 above (below 256 low-resolution rows the f32 planner finds no split that fills the

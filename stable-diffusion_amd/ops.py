@@ -40,38 +40,41 @@ def _p(t):
 
 class LaunchTimer:
     """Optional per-launch timing with HIP events recorded on the launch stream (used by
-    bench.py's roofline leg; None in normal operation).  records: (kind, work, start, end) with
-    ``work`` = algorithmic FLOPs (MFMA kernels) or bytes (bandwidth kernels) of that launch."""
+    bench.py's roofline leg; None in normal operation).  records: (kind, work, start, end, shape, bytes) with
+    ``work`` = algorithmic FLOPs of the REFERENCE's op (MFMA kernels: 2*M*N*K of the nn.Linear / nn.Conv2d the
+    launch stands for -- the hi|lo operand doubling and the 4/9-MAC upsample form are not credited) or bytes
+    (bandwidth kernels), ``bytes`` = compulsory HBM bytes of the launch (operands + weights + result + residual,
+    each once)."""
 
     def __init__(self):
         self.records = []
 
-    def summary(self):
+    def _fold(self, key_of):
         torch.cuda.synchronize()
         out = {}
-        for kind, work, s, e, _ in self.records:
-            ent = out.setdefault(kind, {"launches": 0, "ms": 0.0, "work": 0.0})
+        for rec in self.records:
+            kind, work, s, e, shape, nbytes = rec
+            ent = out.setdefault(key_of(kind, shape), {"launches": 0, "ms": 0.0, "work": 0.0, "bytes": 0.0, "times_ms": []})
+            dt = s.elapsed_time(e)
             ent["launches"] += 1
-            ent["ms"] += s.elapsed_time(e)
+            ent["ms"] += dt
             ent["work"] += work
+            ent["bytes"] += nbytes
+            ent["times_ms"].append(dt)
         return out
 
+    def summary(self):
+        return self._fold(lambda kind, shape: kind)
+
     def by_shape(self):
-        """{(kind, shape): {"launches", "ms", "work"}} -- per problem size, for tuning."""
-        torch.cuda.synchronize()
-        out = {}
-        for kind, work, s, e, shape in self.records:
-            ent = out.setdefault((kind, shape), {"launches": 0, "ms": 0.0, "work": 0.0})
-            ent["launches"] += 1
-            ent["ms"] += s.elapsed_time(e)
-            ent["work"] += work
-        return out
+        """{(kind, shape): {"launches", "ms", "work", "bytes"}} -- per problem size, for tuning."""
+        return self._fold(lambda kind, shape: (kind, shape))
 
 
 PROFILER = None
 
 
-def _timed(kind, work, launch, shape=""):
+def _timed(kind, work, launch, shape="", nbytes=0.0):
     prof = PROFILER
     if prof is None:
         return launch()
@@ -79,7 +82,7 @@ def _timed(kind, work, launch, shape=""):
     s.record()
     r = launch()
     e.record()
-    prof.records.append((kind, float(work), s, e, shape))
+    prof.records.append((kind() if callable(kind) else kind, float(work), s, e, shape() if callable(shape) else shape, float(nbytes)))
     return r
 
 
@@ -98,10 +101,16 @@ GEMM_WS_BYTES = 64 << 20
 
 
 def _gemm_workspace(device):
-    """Per (device, stream) scratch for split-K partial sums (sdamd_gemm / sdamd_conv3x3 `ws`)."""
-    key = (device, torch.cuda.current_stream().cuda_stream)
+    """Per-device scratch for split-K partial sums (sdamd_gemm / sdamd_conv3x3 `ws`), allocated once and never freed
+    or replaced, so a captured hipGraph that holds its address stays valid.  Use is stream-ordered: the package
+    launches on one stream per process (torch's current stream, or the capture stream while a graph is recorded);
+    launches that overlap in time on two streams of one device must not share it."""
+    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
     ws = _gemm_ws.get(key)
     if ws is None:
+        if torch.cuda.is_current_stream_capturing():
+            raise _lib.SdamdError("split-K workspace requested for the first time under graph capture: run the ops once "
+                                  "(or ops.ensure_workspaces) before capturing")
         ws = torch.empty(GEMM_WS_BYTES, dtype=torch.uint8, device=device)
         _gemm_ws[key] = ws
     return ws
@@ -112,21 +121,38 @@ def _dt(dtype):
 
 
 _gn_ws = {}
+_gn_ws_retired = []      # outgrown buffers stay alive: an earlier captured graph may still point at them
+GN_WS_MIN_BYTES = 8 << 20   # 256 samples
 
 
 def _groupnorm_ws(batch, device):
-    key = (device, torch.cuda.current_stream().cuda_stream)
+    """Per-device GroupNorm partial-statistics scratch (same lifetime / stream rules as _gemm_workspace)."""
+    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
     need = _lib.lib().sdamd_groupnorm_ws_bytes(batch)
     ws = _gn_ws.get(key)
     if ws is None or ws.numel() < need:
-        ws = torch.empty(max(need, 1 << 20), dtype=torch.uint8, device=device)
+        if torch.cuda.is_current_stream_capturing():
+            raise _lib.SdamdError("GroupNorm workspace (re)allocation under graph capture: run the ops once "
+                                  "(or ops.ensure_workspaces) before capturing")
+        if ws is not None:
+            _gn_ws_retired.append(ws)
+        ws = torch.empty(max(need, GN_WS_MIN_BYTES), dtype=torch.uint8, device=device)
         _gn_ws[key] = ws
     return ws
 
 
+def ensure_workspaces(device, batch=1):
+    """Allocate the per-device scratch buffers ahead of a graph capture."""
+    _gemm_workspace(device)
+    _groupnorm_ws(batch, device)
+
+
 # ------------------------------------------------------------------ sampler
-def cfg_ddpm_step(latents, eps, noise, coef, step, cfg_scale, do_cfg=True, step_ptr=None):
-    """In-place on ``latents`` [B,4,h,w] f32; eps [2B,4,h,w] f32 ([pos..., neg...])."""
+def cfg_ddpm_step(latents, eps, noise, coef, step, cfg_scale, do_cfg=True, step_ptr=None, deterministic=False):
+    """In-place on ``latents`` [B,4,h,w] f32; eps [2B,4,h,w] f32 ([pos..., neg...]).  ``noise`` may only be None
+    for a schedule the caller has checked to be noise-free (``deterministic=True``: every coef[:, 5] == 0); the
+    kernel reads a null noise pointer as "no noise".  A device-side index (``step_ptr``) outside the schedule makes
+    the launch a no-op."""
     _dev(latents, eps, coef)
     B = latents.shape[0]
     n = latents[0].numel()
@@ -136,14 +162,18 @@ def cfg_ddpm_step(latents, eps, noise, coef, step, cfg_scale, do_cfg=True, step_
     assert coef.dim() == 2 and coef.shape[1] == 8
     if noise is not None:
         assert noise.dtype == torch.float32 and noise.is_contiguous() and noise.numel() == coef.shape[0] * B * n
+    elif not deterministic:
+        raise _lib.SdamdError("cfg_ddpm_step: noise=None needs deterministic=True (a coefficient table with has_noise == 0 "
+                              "in every row); a stochastic sampler must pass its pre-drawn noise")
     if step_ptr is not None:
         assert step_ptr.dtype == torch.int32 and step_ptr.is_cuda
-    else:
-        assert 0 <= step < coef.shape[0]
+    elif not 0 <= step < coef.shape[0]:
+        raise IndexError(f"cfg_ddpm_step: step {step} outside the {coef.shape[0]}-step schedule")
     # algorithmic bytes: 5 x 4*h*w x 4 B per image-step (eps pos/neg, noise, latents in + out)
     _timed("cfg_ddpm_step", 5.0 * B * n * 4,
            lambda: _lib.check(_lib.lib().sdamd_cfg_ddpm_step(_p(latents), _p(eps), _p(noise), _p(coef), _p(step_ptr), int(step),
-                                                             float(cfg_scale), int(do_cfg), B, n, _stream())), f"B{B} n{n}")
+                                                             coef.shape[0], float(cfg_scale), int(do_cfg), B, n, _stream())),
+           f"B{B} n{n}")
     return latents
 
 
@@ -166,9 +196,10 @@ def gather_row(dst, table, step=0, step_ptr=None):
     _dev(dst, table)
     assert dst.dtype == torch.float32 and table.dtype == torch.float32 and table.dim() == 2
     assert dst.numel() == table.shape[1] and dst.is_contiguous() and table.is_contiguous()
-    if step_ptr is None:
-        assert 0 <= step < table.shape[0]
-    _lib.check(_lib.lib().sdamd_gather_row(_p(dst), _p(table), _p(step_ptr), int(step), table.shape[1], _stream()))
+    if step_ptr is None and not 0 <= step < table.shape[0]:
+        raise IndexError(f"gather_row: row {step} outside the {table.shape[0]}-row table")
+    _lib.check(_lib.lib().sdamd_gather_row(_p(dst), _p(table), _p(step_ptr), int(step), table.shape[0], table.shape[1],
+                                           _stream()))
     return dst
 
 
@@ -197,7 +228,7 @@ def groupnorm(x, gamma, beta, eps, silu, out_dtype=None, x2=None):
     else:
         call = lambda: _lib.check(L.sdamd_groupnorm_nhwc_cat(_p(x), _p(x2), C1, C2, _p(y), _p(gamma), _p(beta), _p(ws), B, HW,
                                                              float(eps), int(silu), _code(x.dtype), _code(out_dtype), _stream()))
-    _timed(f"groupnorm_{_dt(x.dtype)}", B * HW * C * (2 * x.element_size() + y.element_size()),   # stats read + apply read + write
+    _timed(f"groupnorm_{_dt(x.dtype)}", B * HW * C * (x.element_size() + y.element_size()),   # 1 read + 1 write per element
            call, f"B{B} HW{HW} C{C}" + (" cat" if x2 is not None else ""))
     return y
 
@@ -390,10 +421,12 @@ def gemm_hilo_fused(M, N, K, dtype):
     return tile in (128160, 128320, 256256)      # the LDS-DMA tiles (gemm2.hip); the 4-wave ones have no such epilogue
 
 
-def gemm(a, w, bias=None, residual=None, act=ACT_NONE, out_f32=False, out_hilo=False):
+def gemm(a, w, bias=None, residual=None, act=ACT_NONE, out_f32=False, out_hilo=False, flops_k=None):
     """a [..., K] (last dim contiguous, uniform row stride), w [N, K] -> [..., N].  The result (and the
     residual, which must have the result's dtype) is f32 when ``out_f32``, else a's dtype.
-    ``out_hilo``: f32 residual, result bf16 [..., 2N] = [bf16(v) | bf16(v - bf16(v))] (see split_hilo)."""
+    ``out_hilo``: f32 residual, result bf16 [..., 2N] = [bf16(v) | bf16(v - bf16(v))] (see split_hilo).
+    ``flops_k``: the K of the reference's op when it differs from the executed one (hi|lo operands run 2K), for the
+    profiler's algorithmic-FLOP credit only."""
     _dev(a, w, bias, residual)
     K = a.shape[-1]
     N = w.shape[0]
@@ -423,11 +456,14 @@ def gemm(a, w, bias=None, residual=None, act=ACT_NONE, out_f32=False, out_hilo=F
     if bias is not None:
         assert bias.dtype == torch.float32 and bias.numel() == N and bias.is_contiguous()
     ws = _gemm_workspace(a.device)
-    _timed(f"gemm_{_dt(a.dtype)}_{_tile_tag(M, N, K, a.dtype, ws, 1, act, residual is not None and res_dtype == torch.float32)}" if PROFILER is not None else "", 2.0 * M * N * K,
+    nbytes = (M * K + N * K) * a.element_size() + out.numel() * out.element_size() + (0 if residual is None else residual.numel() * residual.element_size())
+    _timed(lambda: f"gemm_{_dt(a.dtype)}_{_tile_tag(M, N, K, a.dtype, ws, 1, act, residual is not None and res_dtype == torch.float32)}",
+           2.0 * M * N * (K if flops_k is None else flops_k),
            lambda: _lib.check(_lib.lib().sdamd_gemm(_p(a), _p(w), _p(out), _p(bias), _p(residual), M, N, K, lda, K, n_out, ldr, 1,
                                                     0, 0, 0, 0, int(act), _code(a.dtype), int(out_f32), _p(ws), ws.numel(),
                                                     _stream())),
-           f"M{M} N{N} K{K}{' +res' if residual is not None else ''}{' hilo' if out_f32 == 2 else ' f32out' if out_f32 else ''}{' geglu' if act == ACT_GEGLU else ''}")
+           lambda: f"M{M} N{N} K{K}{' +res' if residual is not None else ''}{' hilo' if out_f32 == 2 else ' f32out' if out_f32 else ''}{' geglu' if act == ACT_GEGLU else ''}",
+           nbytes)
     return out
 
 
@@ -457,8 +493,10 @@ def bmm_nt(a, b, out_f32=False):
     return out
 
 
-def conv3x3(x, w, bias, residual=None, stride=1, pad_mode=0, upsample=False, act=ACT_NONE, out_f32=False):
-    """x [B,H,W,Cin] NHWC, w [Cout, 9*Cin] ([Cout][ky][kx][Cin]) -> [B,Ho,Wo,Cout]."""
+def conv3x3(x, w, bias, residual=None, stride=1, pad_mode=0, upsample=False, act=ACT_NONE, out_f32=False, flops_cin=None):
+    """x [B,H,W,Cin] NHWC, w [Cout, 9*Cin] ([Cout][ky][kx][Cin]) -> [B,Ho,Wo,Cout].
+    ``flops_cin``: the reference conv's Cin when the executed operand is its hi|lo split (2*Cin), for the profiler's
+    algorithmic-FLOP credit only."""
     _dev(x, w, bias, residual)
     assert x.is_contiguous() and x.dim() == 4 and w.is_contiguous() and w.dtype == x.dtype
     B, H, W, Cin = x.shape
@@ -481,25 +519,29 @@ def conv3x3(x, w, bias, residual=None, stride=1, pad_mode=0, upsample=False, act
         assert bias.dtype == torch.float32 and bias.numel() == Cout
     M = B * Ho * Wo
     ws = _gemm_workspace(x.device)
-    _timed(f"conv3x3_{_dt(x.dtype)}_{_tile_tag(M, Cout, 9 * Cin, x.dtype, ws, f32_residual=residual is not None and out.dtype == torch.float32, conv=True)}" if PROFILER is not None else "", 2.0 * M * Cout * 9 * Cin,   # algorithmic (reference) FLOPs, also for the 4/9-MAC phase form
+    nbytes = (x.numel() + w.numel()) * x.element_size() + out.numel() * out.element_size() * (1 if residual is None else 2)
+    # algorithmic FLOPs = the reference's nn.Conv2d (3x3 taps, un-split Cin), also for the 4/9-MAC phase form
+    _timed(lambda: f"conv3x3_{_dt(x.dtype)}_{_tile_tag(M, Cout, 9 * Cin, x.dtype, ws, f32_residual=residual is not None and out.dtype == torch.float32, conv=True)}",
+           2.0 * M * Cout * 9 * (Cin if flops_cin is None else flops_cin),
            lambda: _lib.check(_lib.lib().sdamd_conv3x3(_p(x), _p(w), _p(out), _p(bias), _p(residual), B, H, W, Cin, Cout, stride,
                                                        pad_mode, upsample, int(act), _code(x.dtype), int(out_f32),
                                                        _p(ws), ws.numel(), _stream())),
-           f"M{M} N{Cout} K{9 * Cin} s{stride}{' up' if upsample else ''}{' +res' if residual is not None else ''}{' f32out' if out_f32 else ''}")
+           lambda: f"M{M} N{Cout} K{9 * Cin} s{stride}{' up' if upsample else ''}{' +res' if residual is not None else ''}{' f32out' if out_f32 else ''}",
+           nbytes)
     return out
 
 
-def conv3x3_cin_small(x_nchw, w, bias, dtype):
-    """x [B,Cin(3|4),H,W] f32 NCHW, w [3,3,Cin,Cout] f32 -> [B,H,W,Cout] dtype."""
+def conv3x3_cin_small(x_nchw, w, bias, dtype, copies=1):
+    """x [B,Cin(3|4),H,W] f32 NCHW, w [3,3,Cin,Cout] f32 -> [copies*B,H,W,Cout] dtype (sample n repeated at n, n+B, ...)."""
     _dev(x_nchw, w, bias)
     x_nchw = x_nchw.contiguous()
     assert x_nchw.dtype == torch.float32 and w.dtype == torch.float32 and bias.dtype == torch.float32
     B, Cin, H, W = x_nchw.shape
-    assert w.shape[:3] == (3, 3, Cin) and w.is_contiguous()
+    assert w.shape[:3] == (3, 3, Cin) and w.is_contiguous() and copies >= 1
     Cout = w.shape[3]
-    out = torch.empty((B, H, W, Cout), dtype=dtype, device=x_nchw.device)
-    _lib.check(_lib.lib().sdamd_conv3x3_cin_small(_p(x_nchw), _p(w), _p(bias), _p(out), B, H, W, Cin, Cout, _code(dtype),
-                                                  _stream()))
+    out = torch.empty((copies * B, H, W, Cout), dtype=dtype, device=x_nchw.device)
+    _lib.check(_lib.lib().sdamd_conv3x3_cin_small(_p(x_nchw), _p(w), _p(bias), _p(out), B, H, W, Cin, Cout, int(copies),
+                                                  _code(dtype), _stream()))
     return out
 
 
@@ -530,7 +572,7 @@ def attention(q, k, v, n_heads, causal=False):
                                                          q.stride(0), q.stride(1), k.stride(0), k.stride(1), v.stride(0),
                                                          v.stride(1), out.stride(0), out.stride(1), int(causal),
                                                          _code(q.dtype), _stream())),
-           f"B{B} H{n_heads} Sq{Sq} Skv{Skv} d{d}")
+           f"B{B} H{n_heads} Sq{Sq} Skv{Skv} d{d}", (2 * B * Sq * C + 2 * B * Skv * C) * q.element_size())
     return out
 
 

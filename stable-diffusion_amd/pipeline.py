@@ -22,9 +22,15 @@ from .sampler.euler import EulerSampler as _EulerSampler
 
 
 def EulerSampler(generator):
-    """What ``sampler="euler"`` resolves to: the corrected Euler sampler -- the literal reference class has no finite
-    run to offer (sampler/euler.py; both modes are described there)."""
+    """What ``sampler="euler"`` resolves to HERE: the corrected Euler sampler.  A deliberate departure: the reference
+    resolves "euler" to its literal class (pipeline.py:5,74-84), whose ascending schedule divides by zero on the first
+    step and returns non-finite latents (sampler/euler.py; both modes are described there)."""
     return _EulerSampler(generator, corrected=True)
+
+
+def Euler_referenceSampler(generator):
+    """``sampler="euler_reference"``: the reference's EulerSampler to the letter (non-finite from its first step on)."""
+    return _EulerSampler(generator, corrected=False)
 
 WIDTH = 512
 HEIGHT = 512
@@ -68,9 +74,12 @@ class DenoiseLoop:
         self.cfg_scale = float(cfg_scale)
         self.n_steps = len(timesteps)
         self.latents = latents.float().contiguous().clone()
-        self.model_in = torch.empty(((2 if do_cfg else 1) * self.B,) + tuple(latents.shape[1:]), dtype=torch.float32, device=dev)
+        if noise is None and bool((coef[:, 5] != 0).any()):
+            raise ops._lib.SdamdError("DenoiseLoop: the coefficient table has stochastic rows (has_noise != 0) but no "
+                                      "pre-drawn noise was passed")
         self.coef = coef.to(dev).contiguous()
         self.noise = None if noise is None else noise.to(dev).contiguous()
+        self.host_step = 0            # host mirror of the device-side schedule index
         self.counter = torch.zeros(1, dtype=torch.int32, device=dev)
         unet = diffusion.unet
         self.kv = unet.prompt_state(context)
@@ -84,15 +93,15 @@ class DenoiseLoop:
 
     def _body(self):
         ops.gather_row(self.tb_row, self.tb_table, step_ptr=self.counter)
-        B = self.B
-        self.model_in[:B].copy_(self.latents)
-        if self.do_cfg:
-            self.model_in[B:].copy_(self.latents)
-        eps = self.diffusion.run(self.model_in, self.kv, self.tb)
-        ops.cfg_ddpm_step(self.latents, eps, self.noise, self.coef, 0, self.cfg_scale, self.do_cfg, step_ptr=self.counter)
+        # pipeline.py:147 `latents.repeat(2, 1, 1, 1)`: both CFG halves see the same latents, so the UNet's first
+        # conv runs once and writes both copies (no [x; x] tensor is built)
+        eps = self.diffusion.run(self.latents, self.kv, self.tb, copies=2 if self.do_cfg else 1)
+        ops.cfg_ddpm_step(self.latents, eps, self.noise, self.coef, 0, self.cfg_scale, self.do_cfg, step_ptr=self.counter,
+                          deterministic=self.noise is None)
         ops.counter_add(self.counter, 1)
 
     def _capture(self):
+        ops.ensure_workspaces(self.latents.device, (2 if self.do_cfg else 1) * self.B)   # never allocated under capture
         keep = self.latents.clone()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -107,6 +116,7 @@ class DenoiseLoop:
             self._body()
         self.latents.copy_(keep)
         self.counter.zero_()
+        self.host_step = 0
 
     def set_context(self, context):
         """New prompts for an already captured loop: recompute the K|V projections into the
@@ -115,23 +125,80 @@ class DenoiseLoop:
         for key, buf in self.kv.items():
             buf.copy_(fresh[key])
 
+    def rebind(self, context, timesteps, coef, noise, latents):
+        """Re-use the captured graph for another call of the same shape: new prompts, schedule rows, noise and start
+        latents are copied into the buffers the graph reads.  Returns False (nothing changed) when the shapes differ."""
+        if len(timesteps) != self.n_steps or tuple(latents.shape) != tuple(self.latents.shape) or \
+                (noise is None) != (self.noise is None) or tuple(coef.shape) != tuple(self.coef.shape):
+            return False
+        if noise is None and bool((coef[:, 5] != 0).any()):
+            return False
+        self.set_context(context)
+        temb = torch.cat([get_time_embedding(t) for t in timesteps]).to(self.latents.device)
+        self.tb_table.copy_(self.diffusion.unet.time_bias_table(self.diffusion.time_embedding(temb)))
+        self.coef.copy_(coef, non_blocking=True)
+        if noise is not None:
+            self.noise.copy_(noise, non_blocking=True)
+        self.reset(latents)
+        return True
+
     def reset(self, latents, step=0):
         """Restart from ``latents`` at schedule index ``step`` (teacher-forced parity tests)."""
+        if not 0 <= int(step) < self.n_steps:
+            raise IndexError(f"DenoiseLoop.reset: step {step} outside the {self.n_steps}-step schedule")
         self.latents.copy_(latents)
         self.counter.fill_(int(step))
+        self.host_step = int(step)
 
     def step(self):
+        """One denoising step at the current schedule index.  The index lives on the device (graph replay); the
+        host mirrors it and refuses to run past the schedule (the kernels would no-op, see sdamd_cfg_ddpm_step)."""
+        if self.host_step >= self.n_steps:
+            raise IndexError(f"DenoiseLoop.step: all {self.n_steps} steps of the schedule have run; reset() first")
+        self.host_step += 1
         if self.graph is not None:
             self.graph.replay()
         else:
             self._body()
 
     def run(self, trace=None):
-        for _ in range(self.n_steps):
+        for _ in range(self.host_step, self.n_steps):
             self.step()
             if trace is not None:
                 trace.append(self.latents.clone())
         return self.latents
+
+
+_LOOP_CACHE = {}      # generate(): captured DenoiseLoops by problem shape (graph capture is paid once per shape)
+LOOP_CACHE_SIZE = 4
+
+
+def _weights_stamp(module):
+    return tuple((p.data_ptr(), p._version) for p in module.parameters())
+
+
+def _denoise_loop(diffusion, context, timesteps, coef, noise, latents, cfg_scale, do_cfg, use_graph):
+    """A DenoiseLoop for this call: a cached captured loop of the same shape / weights / guidance scale with its
+    tables refreshed in place, or a new one (captured now, kept for the next call)."""
+    if not use_graph:
+        return DenoiseLoop(diffusion, context, timesteps, coef, noise, latents, cfg_scale, do_cfg, False)
+    key = (id(diffusion), diffusion.compute_dtype, tuple(latents.shape), str(latents.device), len(timesteps), bool(do_cfg),
+           float(cfg_scale), noise is None)
+    ent = _LOOP_CACHE.get(key)
+    stamp = _weights_stamp(diffusion)
+    if ent is not None and ent[0] == stamp and ent[1].rebind(context, timesteps, coef, noise, latents):
+        _LOOP_CACHE[key] = _LOOP_CACHE.pop(key)          # most recently used last
+        return ent[1]
+    loop = DenoiseLoop(diffusion, context, timesteps, coef, noise, latents, cfg_scale, do_cfg, True)
+    _LOOP_CACHE.pop(key, None)
+    _LOOP_CACHE[key] = (stamp, loop)
+    while len(_LOOP_CACHE) > LOOP_CACHE_SIZE:
+        _LOOP_CACHE.pop(next(iter(_LOOP_CACHE)))
+    return loop
+
+
+def clear_loop_cache():
+    _LOOP_CACHE.clear()
 
 
 def _resolve_sampler(name):
@@ -180,7 +247,9 @@ def prepare_latents(seeds, sampler_cls, steps, shape, device, encoder=None, imag
         samplers.append(sm)
     if images_u8 is not None:
         enc_noise = torch.stack([sm.draw_noise(shape[1:]) for sm in samplers]).to(device)
-        latents = encoder(ops.uint8_to_image(images_u8), enc_noise)
+        mb = 8      # micro-batch like the decoder: a 512^2 x 128-channel f32 trunk tensor is 134 MB per image
+        latents = torch.cat([encoder(ops.uint8_to_image(images_u8[i:i + mb].contiguous()), enc_noise[i:i + mb].contiguous())
+                             for i in range(0, len(samplers), mb)])
         for sm in samplers:
             (sm.set_strength if strength_semantics == "reference" else sm.set_strength_steps)(strength=strength)
         if len(samplers[0].timesteps) == 0:
@@ -259,7 +328,7 @@ def generate(
             seeds, sampler_cls, steps, shape, device, models.get("encoder") if input_image is not None else None,
             images_u8, strength, strength_semantics)
 
-        loop = DenoiseLoop(models["diffusion"], context, timesteps, coef, noise, latents, cfg_scale, do_cfg, use_graph)
+        loop = _denoise_loop(models["diffusion"], context, timesteps, coef, noise, latents, cfg_scale, do_cfg, use_graph)
         if preview is None:
             final = loop.run(trace)
         else:   # the reference's per-step preview (pipeline.py:156-164) as an opt-in callback
@@ -272,5 +341,5 @@ def generate(
         images = decode_to_uint8(models["decoder"], final)
         out = images.cpu().numpy()
         if return_latents:
-            return (out if batched else out[0]), final
+            return (out if batched else out[0]), final.clone()   # (the loop's own buffer is re-used by the next call)
         return out if batched else out[0]

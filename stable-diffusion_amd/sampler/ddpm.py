@@ -98,7 +98,7 @@ class DDPMSampler:
         eps = model_output.float().contiguous()
         if eps.numel() != out.numel():
             raise ValueError(f"model_output {tuple(model_output.shape)} does not match latents {tuple(latents.shape)}")
-        ops.cfg_ddpm_step(out.view(1, -1), eps.view(1, -1), noise, coef, 0, 0.0, do_cfg=False)
+        ops.cfg_ddpm_step(out.view(1, -1), eps.view(1, -1), noise, coef, 0, 0.0, do_cfg=False, deterministic=noise is None)   # t == 0: has_noise = 0
         return out
 
     def add_noise(self, original_samples: torch.Tensor, timesteps) -> torch.Tensor:

@@ -7,9 +7,12 @@ Two modes, one fused HIP kernel (``sdamd_cfg_ddpm_step``, a coefficient row per 
   ``sqrt(abar_prev)(1-abar_t)/(1-abar_prev)`` and the sample by ``sqrt(1-abar_t)(1-abar_t)/(1-abar_prev)`` plus
   DDPM's posterior noise.  ``step`` is pinned bit for bit to the reference class wherever that is finite
   (tests/golden/euler_step.npz); a whole run is not: the first timestep is 0, whose previous timestep is
-  negative, so ``1 - abar_prev = 0`` and both weights are infinite (the reference's pipeline never imports the
-  class, pipeline.py:4-5, so ``generate(sampler="euler")`` raises ValueError there).
-* ``corrected=True`` (what ``generate(sampler="euler")`` builds) -- the sampler the name promises: descending
+  negative, so ``1 - abar_prev = 0`` and both weights are infinite.  The reference's pipeline DOES import this class
+  (pipeline.py:5) and resolves ``sampler="euler"`` to it (pipeline.py:74-84), so ``generate(sampler="euler")`` there
+  runs the ascending schedule and returns non-finite latents from the first step on.  Here the literal class stays
+  reachable as ``generate(sampler="euler_reference")`` (same non-finite result, for parity of behaviour).
+* ``corrected=True`` (what ``generate(sampler="euler")`` builds HERE: a deliberate departure from the reference,
+  whose ``"euler"`` has no finite run to be faithful to) -- the sampler the name promises: descending
   timesteps and one explicit Euler step per interval of the probability-flow ODE in sigma space,
   ``x/sqrt(abar)`` moving by ``(sigma_prev - sigma_t) * eps`` with ``sigma = sqrt((1-abar)/abar)``; written
   back in the sample's own scale that is ``sqrt(abar_prev) * x0 + sqrt(1 - abar_prev) * eps``: deterministic,

@@ -9,7 +9,7 @@ import torch
 import sd_amd
 from sd_amd import attention, clip, decoder, diffusion, encoder, engine, pipeline, synth
 from oracle import sd_oracle as O
-from conftest import golden, rel_l2, hin
+from conftest import golden, rel_l2, hin, cpu_state_dicts
 
 pytestmark = pytest.mark.gpu
 torch.set_grad_enabled(False)
@@ -22,16 +22,6 @@ DTYPES = [FP32, BF16]
 def build(cls, prefix, *args, **kw):
     m = synth.load_hashed(cls(*args, **kw), prefix)
     return m.to(DEV)
-
-
-@pytest.fixture(scope="module")
-def models():
-    return {
-        "clip": build(clip.CLIP, "clip."),
-        "encoder": build(encoder.VAE_Encoder, "encoder."),
-        "decoder": build(decoder.VAE_Decoder, "decoder."),
-        "diffusion": build(diffusion.Diffusion, "diffusion."),
-    }
 
 
 def with_dtype(m, dtype):
@@ -369,9 +359,7 @@ _ORACLE_CACHE = {}
 
 
 def _cpu_sds(models):
-    if "sd" not in _ORACLE_CACHE:
-        _ORACLE_CACHE["sd"] = {k: {n: t.cpu() for n, t in m.state_dict().items()} for k, m in models.items()}
-    return _ORACLE_CACHE["sd"]
+    return cpu_state_dicts(models)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)

@@ -84,7 +84,7 @@ def test_sampler_step_and_add_noise_match_golden():
             noise = torch.from_numpy(g[f"noise{steps}_{t}"]).to(DEV) if t > 0 else None
             out = lat.clone()
             ops.cfg_ddpm_step(out.view(1, -1), eps.view(1, -1), noise, sm.step_coefficients(t).reshape(1, 8).to(DEV), 0, 0.0,
-                              do_cfg=False)
+                              do_cfg=False, deterministic=noise is None)
             assert np.array_equal(out.cpu().numpy(), g[f"step{steps}_{t}"]), (steps, t)
             # (b) the sampler API draws from its generator in the reference's order (host randn may
             #     differ from the fixture's host by ulps, so tolerance instead of bit equality)
@@ -137,7 +137,7 @@ def test_ddim_step_matches_golden():
         e = 7.5 * (eps[:B] - eps[B:]) + eps[B:]
         want = ((lat - c[1] * e) / c[0]) * c[2] + c[3] * e
         ctr = torch.tensor([si], dtype=torch.int32, device=DEV)
-        got = ops.cfg_ddpm_step(lat.to(DEV).clone(), eps.to(DEV), None, coef.to(DEV), 0, 7.5, step_ptr=ctr).cpu()
+        got = ops.cfg_ddpm_step(lat.to(DEV).clone(), eps.to(DEV), None, coef.to(DEV), 0, 7.5, step_ptr=ctr, deterministic=True).cpu()
         assert torch.equal(got, want), si
     sm = DDIMSampler(torch.Generator().manual_seed(77))
     x = hin("ddim.an", (1, 4, 16, 16)).to(DEV)

@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     handle = ctypes.CDLL(_lib.LIB_PATH)
     for name in declared:
         assert hasattr(handle, name), name
-    assert _lib.lib().sdamd_abi_version() == 2
+    assert _lib.lib().sdamd_abi_version() == 3
     # host-side tile choice (no GPU needed): 8-wave LDS-DMA tile for a big f32 GEMM, 4-wave 64x64 for a small one
     assert _lib.lib().sdamd_gemm_tile(65536, 320, 320, 1, 0, 0, 0) == 128320
     assert _lib.lib().sdamd_gemm_tile(512, 1280, 1280, 1, 0, 0, 0) == 64064
@@ -121,7 +121,8 @@ def test_bench_labels_map_to_kernel_symbols():
     assert ks("gemm_bf16_256x256_geglu") == "gemm2_kernel<unsigned short, 256, 256, 2, 4, 2, false, 2>"
     assert ks("gemm_f32_128x160") == "gemm2_kernel<float, 128, 160, 2, 2, 2, false, 0>"
     assert ks("gemm_f32_64x64") == "gemm_kernel<float, 64, 64, false>"
+    assert ks("conv3x3_bf16_256x320") == "gemm2_kernel<unsigned short, 256, 320, 4, 2, 2, true, 0>"
     assert ks("attention_bf16_d40") == "attn_kernel<unsigned short, 40>"
     assert ks("groupnorm_f32") == "groupnorm_f32"
-    traffic = bench.pmc_traffic("gemm2_kernel<unsigned short, 128, 160, 2, 2, 2, true, 0>")
-    assert traffic is None or traffic > 1e8        # profiles/r01_pmc_traffic.json carries the dominant kernel under this name
+    traffic, source = bench.pmc_traffic("gemm2_kernel<unsigned short, 128, 160, 2, 2, 2, true, 0>")
+    assert (traffic is None and source is None) or (traffic > 1e8 and source.endswith("_pmc_traffic.json"))        # profiles/r01_pmc_traffic.json carries the dominant kernel under this name

@@ -6,7 +6,7 @@ imports the reference's modules unmodified, fills them with the hash weights of
 ``stable-diffusion_amd/synth.py`` (same state_dict keys), feeds hash/seeded inputs and
 stores the outputs.  Fixtures are data only -- no reference source is copied.
 
-    python tools/gen_golden.py [keys] [small] [models] [pipe3] [img2img] [pipe50] [converter] [ddim] [nocfg] [euler] [fp16]
+    python tools/gen_golden.py [keys] [small] [models] [pipe3] [img2img] [pipe50] [converter] [ddim] [nocfg] [euler] [fp16] [img2img50] [pipe50b]
 """
 import contextlib
 import io
@@ -185,11 +185,11 @@ class _Trace:
         RefDDPM.step = self._orig
 
 
-def gen_pipeline(steps, name, every=1, **kw):
+def gen_pipeline(steps, name, every=1, prompt="synthetic:0", seed=42, **kw):
     m = ref_models()
     t0 = time.time()
     with _Trace() as tr:
-        img = quiet(ref_pipeline.generate, "synthetic:0", "", models=m, seed=42, device="cpu",
+        img = quiet(ref_pipeline.generate, prompt, "", models=m, seed=seed, device="cpu",
                     sampler="ddpm", steps=steps, cfg_scale=7.5, tokenizer=synth.SyntheticTokenizer(), **kw)
     print(f"  reference generate({steps} steps) {time.time() - t0:.0f}s", flush=True)
     lat = torch.stack(tr.latents)
@@ -349,6 +349,15 @@ def main():
         gen_pipeline(2, "pipeline_txt2img_2step")     # the same run in fp32: what the fp16 mode deviates from
     if "pipe50" in what:
         gen_pipeline(50, "pipeline_txt2img_50step", every=1)
+    if "img2img50" in what:
+        # BASELINE config 4's schedule (50 steps, "strength 0.8" as intended = the last 40 steps, from t = 780) out of the
+        # UNMODIFIED reference: called with strength=0.99 its literal set_strength (ddpm.py:50-53) slices exactly
+        # timesteps[10:].  Input image: uniform uint8 noise, seed 7.
+        from PIL import Image
+        pil = Image.fromarray(np.random.default_rng(7).integers(0, 256, (512, 512, 3), dtype=np.uint8))
+        gen_pipeline(50, "pipeline_img2img_50step_s099", every=5, input_image=pil, strength=0.99)
+    if "pipe50b" in what:    # a second seed / prompt for the 50-step free-running bf16 budget
+        gen_pipeline(50, "pipeline_txt2img_50step_seed43", every=5, prompt="synthetic:1", seed=43)
 
 
 if __name__ == "__main__":
