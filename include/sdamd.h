@@ -167,7 +167,9 @@ int sdamd_conv3x3_cout_small(const void* x_nhwc, const void* w_packed, const flo
 
 /* ---- MFMA flash attention: attention.py:47-68 (self, optional causal) and :112-127 (cross);
  * replaces customtriton.py / flash_attention.py outright.  q/k/v/out are [B][S][row stride]
- * with head h at columns [h*d,(h+1)*d); strides in elements; d in {40,64,80,160}. */
+ * with head h at columns [h*d,(h+1)*d); strides in elements; d in {40,64,80,160} (UNet / CLIP
+ * heads) or 512 (the VAE's single head, decoder.py:39-70: the head dim is split over the
+ * workgroup's waves, non-causal only).  No [S,S] tensor is materialised for any d. */
 int sdamd_attention(const void* q, const void* k, const void* v, void* out, int B, int H, int Sq,
                     int Skv, int d, long long q_bs, int q_rs, long long k_bs, int k_rs,
                     long long v_bs, int v_rs, long long o_bs, int o_rs, int causal, int dtype,

@@ -377,12 +377,253 @@ static int launch_attn(const AttnArgs& a, int B, hipStream_t st) {
   return 0;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Flash attention for the VAE's single 512-wide head (decoder.py:39-70 -> attention.py:46-68; S = 4096 at 512^2,
+// 9216 at 768^2).  An O^T accumulator of 512 rows x 32 queries does not fit one wave's registers, so the head dim is
+// split over the workgroup's 4 waves ("split-d accumulators"):
+//   workgroup = 32 queries of one (batch, head); wave w owns head-dim slice [128w, 128w+128)
+//   per 32-key tile:  S^T_w = K[:, slice] Q[:, slice]^T      (partial scores over the wave's slice of the contraction)
+//                     partials exchanged through LDS, every wave sums the four -> full S^T (same order in every wave,
+//                     so all four waves hold bit-identical scores and soft-max state)
+//                     online softmax (redundant per wave: 16 exp per lane)
+//                     O^T[slice] += V[:, slice]^T P^T         (the wave's 128 output columns)
+// No [S, S] tensor exists anywhere.  bf16: 32x32x16 MFMA, K/V tiles double-buffered (register prefetch), V^T via
+// ds_read_b64_tr_b16.  f32: exact 32x32x2 MFMA, one stage (a 32-key f32 tile of K and V is 128 KB).
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void attn512_kernel(const AttnArgs p) {
+  constexpr int D = 512, SL = 128;                       // head dim, per-wave slice
+  constexpr bool BF = sizeof(T) == 2;
+  constexpr int EPC = 16 / sizeof(T);
+  constexpr int KS = D * (int)sizeof(T) + 16;            // K row stride (bytes): odd multiple of 16
+  constexpr int VS = BF ? D * 2 + 64 : D * 4;            // V row stride (bf16: 4 rows x 64 B tile a bank row for the transposed read)
+  constexpr int BKV = 32;
+  constexpr int STAGES = BF ? 2 : 1;
+  constexpr int STAGE = BKV * (KS + VS);
+  constexpr int DC = D / EPC;                            // 16-byte chunks per row
+  constexpr int NCH = BKV * DC;                          // chunks per K (or V) tile
+  constexpr int PT = NCH / 256;                          // chunks per thread
+  constexpr int NQ = BF ? SL / 16 : SL / 8;              // Q fragments of the wave's slice (4 VGPR each)
+  constexpr int NB = SL / 32;                            // 32-row output blocks of the wave's slice
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const xs = smem + STAGES * STAGE;                // partial-score exchange: [4 waves][4][64 lanes][16 B]
+
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  const int b = blockIdx.y / p.H, head = blockIdx.y % p.H;
+  const int q0 = blockIdx.x * 32;
+  const int qrow = q0 + r;
+  const T* __restrict__ Qp = (const T*)p.Q + (size_t)b * p.q_bs + (size_t)head * D;
+  const T* __restrict__ Kp = (const T*)p.K + (size_t)b * p.k_bs + (size_t)head * D;
+  const T* __restrict__ Vp = (const T*)p.V + (size_t)b * p.v_bs + (size_t)head * D;
+  const int d_w = wave * SL;
+
+  u32x4_t qf[NQ];
+  {
+    const T* qr = Qp + (size_t)min(qrow, p.Sq - 1) * p.q_rs + d_w;
+#pragma unroll
+    for (int s = 0; s < NQ; ++s) qf[s] = *reinterpret_cast<const u32x4_t*>(qr + (BF ? 16 * s + 8 * h : 8 * s + 4 * h));
+  }
+
+  u32x4_t rk[BF ? PT : 1], rv[BF ? PT : 1];              // bf16: register prefetch of the next tile
+  auto issue = [&](int kv0) {
+#pragma unroll
+    for (int i = 0; i < PT; ++i) {
+      const int c = t + 256 * i, row = c / DC, ch = c - row * DC;
+      const size_t grow = (size_t)min(kv0 + row, p.Skv - 1);
+      rk[i] = *reinterpret_cast<const u32x4_t*>(Kp + grow * p.k_rs + ch * EPC);
+      rv[i] = *reinterpret_cast<const u32x4_t*>(Vp + grow * p.v_rs + ch * EPC);
+    }
+  };
+  auto commit = [&](int stage) {
+    char* ks = smem + stage * STAGE;
+    char* vs = ks + BKV * KS;
+#pragma unroll
+    for (int i = 0; i < PT; ++i) {
+      const int c = t + 256 * i, row = c / DC, ch = c - row * DC;
+      *reinterpret_cast<u32x4_t*>(ks + row * KS + ch * 16) = rk[i];
+      *reinterpret_cast<u32x4_t*>(vs + row * VS + ch * 16) = rv[i];
+    }
+  };
+  auto load_sync = [&](int kv0) {                        // f32: straight through registers, 8 chunks at a time
+    char* ks = smem;
+    char* vs = ks + BKV * KS;
+    for (int i0 = 0; i0 < PT; i0 += 8) {
+      u32x4_t a[8], c8[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int c = t + 256 * (i0 + i), row = c / DC, ch = c - row * DC;
+        const size_t grow = (size_t)min(kv0 + row, p.Skv - 1);
+        a[i] = *reinterpret_cast<const u32x4_t*>(Kp + grow * p.k_rs + ch * EPC);
+        c8[i] = *reinterpret_cast<const u32x4_t*>(Vp + grow * p.v_rs + ch * EPC);
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int c = t + 256 * (i0 + i), row = c / DC, ch = c - row * DC;
+        *reinterpret_cast<u32x4_t*>(ks + row * KS + ch * 16) = a[i];
+        *reinterpret_cast<u32x4_t*>(vs + row * VS + ch * 16) = c8[i];
+      }
+    }
+  };
+
+  f32x16_t o[NB];
+#pragma unroll
+  for (int i = 0; i < NB; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) o[i][e] = 0.f;
+  float m_run = -1.0e30f, l_run = 0.f;
+  const int ntiles = (p.Skv + BKV - 1) / BKV;
+  const float sc = p.scale_log2e;
+
+  if constexpr (BF) { issue(0); commit(0); } else { load_sync(0); }
+  __syncthreads();
+  for (int kt = 0; kt < ntiles; ++kt) {
+    const int kv0 = kt * BKV;
+    const char* ks = smem + (BF ? (kt & 1) : 0) * STAGE;
+    const char* vs = ks + BKV * KS;
+    if constexpr (BF) { if (kt + 1 < ntiles) issue(kv0 + BKV); }
+
+    // partial scores over this wave's slice of the head dim
+    f32x16_t s;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) s[e] = 0.f;
+    if constexpr (BF) {
+#pragma unroll
+      for (int st = 0; st < NQ; ++st) {
+        bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(ks + r * KS + (d_w + 16 * st + 8 * h) * 2);
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, __builtin_bit_cast(bf16x8_t, qf[st]), s, 0, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int g = 0; g < NQ; ++g) {
+        f32x4_t kf = *reinterpret_cast<const f32x4_t*>(ks + r * KS + (d_w + 8 * g + 4 * h) * 4);
+        f32x4_t qv = __builtin_bit_cast(f32x4_t, qf[g]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[e], qv[e], s, 0, 0, 0);
+      }
+    }
+    // exchange: every wave publishes its partial, then sums the four in wave order 0..3
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      *reinterpret_cast<f32x4_t*>(xs + wave * 4096 + g * 1024 + lane * 16) = (f32x4_t){s[4 * g], s[4 * g + 1], s[4 * g + 2], s[4 * g + 3]};
+    __syncthreads();
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      f32x4_t a = *reinterpret_cast<const f32x4_t*>(xs + 0 * 4096 + g * 1024 + lane * 16);
+#pragma unroll
+      for (int w = 1; w < 4; ++w) a += *reinterpret_cast<const f32x4_t*>(xs + w * 4096 + g * 1024 + lane * 16);
+      s[4 * g] = a[0]; s[4 * g + 1] = a[1]; s[4 * g + 2] = a[2]; s[4 * g + 3] = a[3];
+    }
+    // online softmax in the log2 domain (register e of lane (r, h) = key (e&3) + 8*(e>>2) + 4h, query r)
+    if (kv0 + BKV > p.Skv) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e)
+        if (kv0 + (e & 3) + 8 * (e >> 2) + 4 * h >= p.Skv) s[e] = -1.0e30f;
+    }
+    float mx = -1.0e30f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) mx = fmaxf(mx, s[e]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx * sc);
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    float rs = 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { s[e] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[e], sc, -m_new)); rs += s[e]; }
+    rs += __shfl_xor(rs, 32, 64);
+    l_run = __builtin_fmaf(l_run, alpha, rs);
+    m_run = m_new;
+    if (!__all(alpha == 1.0f)) {
+#pragma unroll
+      for (int i = 0; i < NB; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[i][e] *= alpha;
+    }
+    // O^T[slice] += V[:, slice]^T P^T
+    if constexpr (BF) {
+      const int g16 = lane >> 4, li = lane & 15;
+      const char* vbase = vs + (4 * (g16 >> 1) + (li >> 2)) * VS + (d_w + 16 * (g16 & 1) + 4 * (li & 3)) * 2;
+      bf16x8_t pf[2];
+#pragma unroll
+      for (int st = 0; st < 2; ++st) {
+        u32x4_t w;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) w[j] = pack_bf2(s[8 * st + 2 * j], s[8 * st + 2 * j + 1]);
+        pf[st] = __builtin_bit_cast(bf16x8_t, w);
+      }
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+          s16x4_t lo = lds_read_tr16(vbase + (16 * st) * VS + i * 64);
+          s16x4_t hi = lds_read_tr16(vbase + (16 * st + 8) * VS + i * 64);
+          typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+          s16x8_t vv = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          o[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, vv), pf[st], o[i], 0, 0, 0);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int key = (e & 3) + 8 * (e >> 2) + 4 * h;
+          float a = *reinterpret_cast<const float*>(vs + key * VS + (d_w + i * 32 + r) * 4);
+          o[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, s[e], o[i], 0, 0, 0);
+        }
+      }
+    }
+    if constexpr (BF) {
+      if (kt + 1 < ntiles) commit((kt + 1) & 1);
+      __syncthreads();                                   // next tile visible; everyone is done with xs and this tile
+    } else {
+      __syncthreads();                                   // everyone is done with the (single) tile and xs
+      if (kt + 1 < ntiles) { load_sync(kv0 + BKV); __syncthreads(); }
+    }
+  }
+
+  if (qrow < p.Sq) {
+    const float inv = 1.0f / l_run;
+    T* op = (T*)p.O + (size_t)b * p.o_bs + (size_t)qrow * p.o_rs + (size_t)head * D + d_w;
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d0 = 32 * i + 8 * g + 4 * h;
+        float v0 = o[i][4 * g] * inv, v1 = o[i][4 * g + 1] * inv, v2 = o[i][4 * g + 2] * inv, v3 = o[i][4 * g + 3] * inv;
+        if constexpr (BF) {
+          u32x2_t w = {pack_bf2(v0, v1), pack_bf2(v2, v3)};
+          *reinterpret_cast<u32x2_t*>(op + d0) = w;
+        } else {
+          *reinterpret_cast<f32x4_t*>(op + d0) = (f32x4_t){v0, v1, v2, v3};
+        }
+      }
+    }
+  }
+}
+
+template <typename T>
+static int launch_attn512(const AttnArgs& a, int B, hipStream_t st) {
+  constexpr bool BF = sizeof(T) == 2;
+  constexpr int KS = 512 * (int)sizeof(T) + 16, VS = BF ? 512 * 2 + 64 : 512 * 4;
+  constexpr int lds = (BF ? 2 : 1) * 32 * (KS + VS) + 4 * 4096;
+  static_assert(lds <= 160 * 1024, "attn512: LDS budget");
+  static std::atomic<unsigned long long> lds_ok{0};
+  if (sd_lds_opt_in(lds_ok, (const void*)attn512_kernel<T>, lds) != hipSuccess)
+    return sdamd_set_error(2, "attention(d=512): cannot reserve %d bytes of LDS", lds);
+  dim3 grid((a.Sq + 31) / 32, B * a.H);
+  attn512_kernel<T><<<grid, 256, lds, st>>>(a);
+  SD_LAUNCH_CHECK("attention512");
+  return 0;
+}
+
 // q/k/v/out: [B][S][row stride] with head h at columns [h*d, (h+1)*d); strides in elements.
 extern "C" int sdamd_attention(const void* q, const void* k, const void* v, void* out, int B, int H, int Sq, int Skv, int d,
                                long long q_bs, int q_rs, long long k_bs, int k_rs, long long v_bs, int v_rs,
                                long long o_bs, int o_rs, int causal, int dtype, void* stream) {
   SD_CHECK(B > 0 && H > 0 && Sq > 0 && Skv > 0, "attention: empty problem B=%d H=%d Sq=%d Skv=%d", B, H, Sq, Skv);
-  SD_CHECK(d == 40 || d == 64 || d == 80 || d == 160, "attention: head dim %d not built (40, 64, 80, 160)", d);
+  SD_CHECK(d == 40 || d == 64 || d == 80 || d == 160 || d == 512, "attention: head dim %d not built (40, 64, 80, 160, 512)", d);
+  SD_CHECK(d != 512 || !causal, "attention: the 512-wide head (VAE) has no causal form");
   SD_CHECK(dtype == SDAMD_BF16 || dtype == SDAMD_F32, "attention: bad dtype");
   const int esz = dtype == SDAMD_BF16 ? 2 : 4;
   SD_CHECK(((uintptr_t)q % 16) == 0 && ((uintptr_t)k % 16) == 0 && ((uintptr_t)v % 16) == 0 && ((uintptr_t)out % 16) == 0,
@@ -399,6 +640,7 @@ extern "C" int sdamd_attention(const void* q, const void* k, const void* v, void
   a.causal = causal;
   { extern int g_gemm_debug; a.debug = g_gemm_debug; }
   hipStream_t st = (hipStream_t)stream;
+  if (d == 512) return dtype == SDAMD_BF16 ? launch_attn512<bf16_t>(a, B, st) : launch_attn512<float>(a, B, st);
 #define ATT(TT) switch (d) { case 40: return launch_attn<TT, 40>(a, B, st); case 64: return launch_attn<TT, 64>(a, B, st); \
                              case 80: return launch_attn<TT, 80>(a, B, st); default: return launch_attn<TT, 160>(a, B, st); }
   if (dtype == SDAMD_BF16) ATT(bf16_t) else ATT(float)

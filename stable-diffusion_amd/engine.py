@@ -216,17 +216,12 @@ def layernorm(x, ln, out_dtype=None):
 
 
 def self_attention(x, attn, causal=False, residual=None):
-    """attention.py:25-75 on token-major x [B,S,C]: fused QKV GEMM -> flash attention (or the
-    GEMM/softmax/GEMM form for the 512-wide single VAE head) -> out-proj GEMM (+ residual, whose
-    dtype the result takes)."""
+    """attention.py:25-75 on token-major x [B,S,C]: fused QKV GEMM -> flash attention -> out-proj GEMM
+    (+ residual, whose dtype the result takes)."""
     qkv = linear(x, attn.in_proj)
     C = x.shape[-1]
     q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
-    if attn.d_head > 160:
-        assert attn.n_heads == 1 and not causal
-        o = ops.attention_unfused(q, k, v)
-    else:
-        o = ops.attention(q, k, v, attn.n_heads, causal)
+    o = ops.attention(q, k, v, attn.n_heads, causal)   # one flash kernel family, the VAE's 512-wide head included
     return linear(o, attn.out_proj, residual)
 
 

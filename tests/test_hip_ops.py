@@ -476,7 +476,8 @@ def test_small_channel_convs(dtype):
 @pytest.mark.parametrize("B,H,d,Sq,Skv,causal", [
     (2, 8, 40, 256, 256, False), (1, 8, 40, 1024, 1024, False), (2, 8, 80, 144, 144, False),
     (2, 8, 160, 64, 64, False), (1, 8, 160, 300, 300, False), (2, 12, 64, 77, 77, True),
-    (2, 8, 40, 256, 77, False), (2, 8, 80, 64, 77, False), (2, 8, 160, 16, 77, False), (1, 8, 40, 100, 33, False)])
+    (2, 8, 40, 256, 77, False), (2, 8, 80, 64, 77, False), (2, 8, 160, 16, 77, False), (1, 8, 40, 100, 33, False),
+    (2, 1, 512, 64, 64, False), (1, 1, 512, 300, 300, False), (1, 2, 512, 40, 77, False)])     # the VAE's 512-wide head (split-d kernel)
 def test_flash_attention(dtype, B, H, d, Sq, Skv, causal):
     C = H * d
     qq = q(rnd(f"att.q.{d}.{Sq}", (B, Sq, C), 1.5), dtype)
@@ -500,6 +501,24 @@ def test_flash_attention_fused_qkv_views_and_spiky_scores(dtype):
     dv = qkv.to(dtype).to(DEV)
     got = ops.attention(dv[..., :C], dv[..., C:2 * C], dv[..., 2 * C:], H)
     assert rel_l2(got.float().cpu(), want) < tol(dtype, 3e-6, 1e-2)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_flash_attention_vae_head_full_size_and_spiky(dtype):
+    """decoder.py:39-70 at its real size (one head of 512, S = 4096 = the 64x64 map of a 512^2 image): strided views of
+    the fused projection, one late dominant key (forces the online softmax of all four d-slice waves to rescale alike).
+    Checked against the CPU oracle on a slice of the queries and against the unfused GEMM / softmax / GEMM form."""
+    B, S, C = 1, 4096, 512
+    qkv = rnd("att.vae.full", (B, S, 3 * C), 0.5)
+    qkv[:, 3000, C:2 * C] *= 6.0
+    qkv = q(qkv, dtype)
+    dv = qkv.to(dtype).to(DEV)
+    got = ops.attention(dv[..., :C], dv[..., C:2 * C], dv[..., 2 * C:], 1)
+    rows = slice(1000, 1256)
+    want = O.attention_core(qkv[:, rows, :C], qkv[..., C:2 * C], qkv[..., 2 * C:], 1)
+    assert rel_l2(got[:, rows].float().cpu(), want) < tol(dtype, 3e-6, 1e-2)
+    unfused = ops.attention_unfused(dv[..., :C], dv[..., C:2 * C], dv[..., 2 * C:])
+    assert rel_l2(got.float().cpu(), unfused.float().cpu()) < tol(dtype, 5e-6, 1.5e-2)
 
 
 def test_argument_errors_are_reported():
