@@ -68,6 +68,19 @@ size_t sdamd_groupnorm_ws_bytes(int B);
 int sdamd_groupnorm_nhwc(const void* x, void* y, const float* gamma, const float* beta, void* ws,
                          int B, int HW, int C, float eps, int silu, int dtype, int out_dtype,
                          void* stream);
+/* The same GroupNorm for callers that cannot allocate or carry a workspace (code under hipGraph
+ * capture, tight serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.
+ * The per-block partial statistics live in a device array built into the library (2 MiB per GPU,
+ * held until the process ends) instead of `ws`; B <= sdamd_groupnorm_noalloc_max_batch() (64),
+ * larger batches are rejected.  Calls no hipMalloc / hipFree / allocating routine.  All calls on one
+ * GPU share the array: calls that overlap in time on one GPU (two streams) race.  The array's
+ * address is looked up on the first call per device (hipGetSymbolAddress, not a stream operation);
+ * sdamd_noalloc_init() does that lookup ahead of time for the current device. */
+int sdamd_noalloc_init(void);
+int sdamd_groupnorm_noalloc_max_batch(void);
+int sdamd_groupnorm_nhwc_noalloc(const void* x, void* y, const float* gamma, const float* beta, int B,
+                                 int HW, int C, float eps, int silu, int dtype, int out_dtype,
+                                 void* stream);
 /* GroupNorm(32, C1+C2) of torch.cat((x1, x2), dim=channel) without materialising the concat: the
  * skip connections of the UNet's up path, diffusion.py:279 followed by :26-28 of the next
  * UNET_ResidualBlock.  x1 [B][HW][C1], x2 [B][HW][C2], y [B][HW][C1+C2]. */

@@ -22,6 +22,9 @@ SIGNATURES = {
     "sdamd_gather_row": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     "sdamd_groupnorm_ws_bytes": (_sz, [_i]),
     "sdamd_groupnorm_nhwc": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _i, _i, _vp]),
+    "sdamd_noalloc_init": (_i, []),
+    "sdamd_groupnorm_noalloc_max_batch": (_i, []),
+    "sdamd_groupnorm_nhwc_noalloc": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _i, _i, _vp]),
     "sdamd_groupnorm_nhwc_cat": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _f, _i, _i, _i, _vp]),
     "sdamd_layernorm": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _i, _i, _vp]),
     "sdamd_softmax_rows": (_i, [_vp, _vp, _i, _i, _f, _i, _vp]),

@@ -3,6 +3,7 @@
 // clip.py:54,63,95 of the reference.  Statistics are accumulated in f64 (deterministic order,
 // no atomics) so fp32 results stay well inside the 1e-4 budget of the whole UNet.
 #include "common.h"
+#include <mutex>
 
 // ---------------------------------------------------------------------------------------------
 // GroupNorm stats: grid (nblk, B), 256 threads.  A block walks a contiguous range of pixels of
@@ -464,6 +465,54 @@ extern "C" int sdamd_groupnorm_nhwc_cat(const void* x1, const void* x2, int C1, 
                                         int out_dtype, void* stream) {
   SD_CHECK(x1 && x2 && C1 > 0 && C2 > 0, "groupnorm_cat: null source or empty half");
   return groupnorm_impl(x1, x2, C1, y, gamma, beta, ws, B, HW, C1 + C2, eps, silu, dtype, out_dtype, stream);
+}
+
+// ---------------------------------------------------------------------------------------------
+// GroupNorm for callers that cannot allocate (code under hipGraph capture, tight serving loops, harnesses that
+// forbid hipMalloc): same kernels as sdamd_groupnorm_nhwc, but the per-block partial statistics live in a
+// file-scope device array instead of a caller workspace.  Every GPU the library runs on holds its own copy of the
+// array (2 MiB) at its own address until the process ends; the address is looked up once per device.
+// Nothing has to start at zero: every slot the apply pass reads was written by the stats pass of the same call.
+// Calls that overlap on one GPU (two streams) share the array and race -- serialise them.
+// ---------------------------------------------------------------------------------------------
+constexpr int GN_NOALLOC_MAXB = 64;                                   // samples per call
+constexpr size_t GN_NOALLOC_DOUBLES = (size_t)GN_NOALLOC_MAXB * 64 * 32 * 2;   // [B][64 blocks][32 groups][sum, sumsq]
+static __device__ __align__(256) double scratch[GN_NOALLOC_DOUBLES];
+
+constexpr int GN_MAX_DEVICES = 64;
+static std::mutex g_scratch_mu;
+static void* g_scratch_ptr[GN_MAX_DEVICES] = {nullptr};
+
+// device address of `scratch` on the current device (looked up on the first call per device); null + error text on failure
+static void* gn_scratch_for_current_device() {
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= GN_MAX_DEVICES) {
+    sdamd_set_error(2, "groupnorm_noalloc: no current HIP device (or device index >= %d)", GN_MAX_DEVICES);
+    return nullptr;
+  }
+  std::lock_guard<std::mutex> lock(g_scratch_mu);
+  if (!g_scratch_ptr[dev]) {
+    void* ptr = nullptr;
+    const hipError_t e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
+    if (e != hipSuccess || !ptr) {
+      sdamd_set_error(2, "groupnorm_noalloc: hipGetSymbolAddress failed on device %d: %s", dev, hipGetErrorString(e));
+      return nullptr;
+    }
+    g_scratch_ptr[dev] = ptr;
+  }
+  return g_scratch_ptr[dev];
+}
+
+extern "C" int sdamd_noalloc_init(void) { return gn_scratch_for_current_device() ? 0 : 2; }
+extern "C" int sdamd_groupnorm_noalloc_max_batch(void) { return GN_NOALLOC_MAXB; }
+
+extern "C" int sdamd_groupnorm_nhwc_noalloc(const void* x, void* y, const float* gamma, const float* beta, int B, int HW,
+                                            int C, float eps, int silu, int dtype, int out_dtype, void* stream) {
+  SD_CHECK(B <= GN_NOALLOC_MAXB, "groupnorm_noalloc: B=%d exceeds the built-in scratch (max %d samples per call); "
+           "split the batch or use sdamd_groupnorm_nhwc with a workspace", B, GN_NOALLOC_MAXB);
+  void* ws = gn_scratch_for_current_device();
+  if (!ws) return 2;
+  return groupnorm_impl(x, nullptr, 0, y, gamma, beta, ws, B, HW, C, eps, silu, dtype, out_dtype, stream);
 }
 
 extern "C" int sdamd_layernorm(const void* x, void* y, const float* gamma, const float* beta, int rows, int C, float eps,
