@@ -87,6 +87,14 @@ int sdamd_groupnorm_nhwc_noalloc(const void* x, void* y, const float* gamma, con
 int sdamd_groupnorm_nhwc_cat(const void* x1, const void* x2, int C1, int C2, void* y,
                              const float* gamma, const float* beta, void* ws, int B, int HW,
                              float eps, int silu, int dtype, int out_dtype, void* stream);
+/* GroupNorm whose statistics come from the GEMM / conv that PRODUCED x (sdamd_gemm / sdamd_conv3x3 `colstats`): the
+ * pass that reads the whole tensor for its statistics is not run (diffusion.py:26-28,38-40,93: the normalised tensor is
+ * the previous conv's / residual add's output).  stats1 [B*HW/64][C1][2] f32, stats2 likewise for the second source of
+ * a virtual concat (x2, C2; null / 0 without one); HW % 64 == 0; ws as for sdamd_groupnorm_nhwc.  Small maps (one-launch
+ * kernel) ignore the statistics. */
+int sdamd_groupnorm_nhwc_pre(const void* x1, const void* x2, int C1, int C2, void* y, const float* gamma,
+                             const float* beta, const float* stats1, const float* stats2, void* ws, int B,
+                             int HW, float eps, int silu, int dtype, int out_dtype, void* stream);
 /* nn.LayerNorm(C): diffusion.py:109,117,126; clip.py:54,63,95; dtypes as for groupnorm */
 int sdamd_layernorm(const void* x, void* y, const float* gamma, const float* beta, int rows, int C,
                     float eps, int dtype, int out_dtype, void* stream);
@@ -140,11 +148,17 @@ int sdamd_vae_sample(const float* x, const float* noise, float* out, const float
  * where the result is only ever read as the hi|lo operand of the next GEMM (linear_geglu_2 ->
  * conv_output, diffusion.py:132-140).  `ws` (may be null) is
  * caller-owned scratch of ws_bytes for split-K partial sums: small-M / large-K problems then
- * spread K over more workgroups and a reduce kernel applies bias/residual/act. */
+ * spread K over more workgroups and a reduce kernel applies bias/residual/act.
+ * `colstats` (may be null): the epilogue also leaves, per 64-row block rb and output column n,
+ * colstats[(rb*N + n)*2 + {0,1}] = sum and sum of squares of the stored C[rb*64..rb*64+63][n] (f32,
+ * ceil(M/64)*N*2 floats) for a GroupNorm that normalises C (sdamd_groupnorm_nhwc_pre).  Only un-split, un-batched
+ * launches on the LDS-DMA kernels with f32 or operand-type output produce them: *colstats_written (host int, may
+ * be null) says whether this call did. */
 int sdamd_gemm(const void* A, const void* W, void* C, const float* bias, const void* residual, int M,
                int N, int K, int lda, int ldw, int ldc, int ldr, int batch, long long strideA,
                long long strideW, long long strideC, long long strideR, int act, int dtype,
-               int out_f32, void* ws, size_t ws_bytes, void* stream);
+               int out_f32, void* ws, size_t ws_bytes, float* colstats, int* colstats_written,
+               void* stream);
 /* block tile the GEMM/conv launcher picks for a problem (BM*1000+BN + 1000000*(splits-1)); host-only helper
  * used by bench.py to attribute launches to kernel instantiations (no reference counterpart) */
 int sdamd_gemm_tile(int M, int N, int K, int batch, int dtype, size_t ws_bytes, int act);
@@ -161,10 +175,12 @@ int sdamd_set_gemm_impl(int impl);
  * (diffusion.py:148-150, decoder.py:90) into the gather; upsample=2 computes the same result as
  * four 2x2 convs, one per output phase (py,px), at 4/9 of the MACs: w is then
  * [4][Cout][2][2][Cin] with the 3x3 taps that read the same input pixel summed (bf16 only);
- * residual [B][Ho][Wo][Cout] or null. */
+ * residual [B][Ho][Wo][Cout] or null.  colstats / colstats_written: as for sdamd_gemm, with
+ * M = B*Ho*Wo rows and N = Cout columns (never for the phase form). */
 int sdamd_conv3x3(const void* x, const void* w, void* y, const float* bias, const void* residual,
                   int B, int H, int W, int Cin, int Cout, int stride, int pad_mode, int upsample,
-                  int act, int dtype, int out_f32, void* ws, size_t ws_bytes, void* stream);
+                  int act, int dtype, int out_f32, void* ws, size_t ws_bytes, float* colstats,
+                  int* colstats_written, void* stream);
 /* first convs (diffusion.py:196, decoder.py:78, encoder.py:10): x NCHW f32 [B], Cin 3|4,
  * w [ky][kx][Cin][Cout] f32 -> y NHWC dtype [copies*B]: sample n is written `copies` times, at
  * n, n+B, ... (copies = 2: the UNet input under classifier-free guidance is the same latents

@@ -25,6 +25,7 @@ SIGNATURES = {
     "sdamd_noalloc_init": (_i, []),
     "sdamd_groupnorm_noalloc_max_batch": (_i, []),
     "sdamd_groupnorm_nhwc_noalloc": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _i, _i, _vp]),
+    "sdamd_groupnorm_nhwc_pre": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _i, _i, _i, _vp]),
     "sdamd_groupnorm_nhwc_cat": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _f, _i, _i, _i, _vp]),
     "sdamd_layernorm": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _i, _i, _vp]),
     "sdamd_softmax_rows": (_i, [_vp, _vp, _i, _i, _f, _i, _vp]),
@@ -43,11 +44,11 @@ SIGNATURES = {
     "sdamd_uint8_to_image": (_i, [_vp, _vp, _i, _i, _vp]),
     "sdamd_vae_post_quant": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
     "sdamd_vae_sample": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
-    "sdamd_gemm": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _ll, _ll, _ll, _ll, _i, _i, _i, _vp, _sz, _vp]),
+    "sdamd_gemm": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _ll, _ll, _ll, _ll, _i, _i, _i, _vp, _sz, _vp, _vp, _vp]),
     "sdamd_gemm_tile": (_i, [_i, _i, _i, _i, _i, _sz, _i]),
     "sdamd_set_gemm_impl": (_i, [_i]),
     "sdamd_gemm_supports_act": (_i, [_i, _i, _i]),
-    "sdamd_conv3x3": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "sdamd_conv3x3": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp, _vp, _vp]),
     "sdamd_conv3x3_cin_small": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "sdamd_conv3x3_cout_small": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "sdamd_attention": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _ll, _i, _ll, _i, _ll, _i, _ll, _i, _i, _i, _vp]),

@@ -406,6 +406,13 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm2_kernel(const GemmArgs p) 
     char* const slice = smem + wave * (IP * 16 * RS);
     const float* __restrict__ Rf = p.R ? (const float*)p.R + (size_t)batch * p.sR : nullptr;
     float* __restrict__ C = (float*)p.C + (size_t)batch * p.sC;
+    // column statistics of the stored values for a following GroupNorm (GemmArgs::colstats): the finished chunks go
+    // back into the wave's LDS slice and every lane then sums one (or two) columns over the pass's rows
+    const bool do_stats = p.colstats != nullptr;
+    constexpr int NCR = (WTN + 63) / 64;
+    float cs[NCR], cq[NCR];
+#pragma unroll
+    for (int k = 0; k < NCR; ++k) { cs[k] = 0.f; cq[k] = 0.f; }
 #pragma unroll
     for (int ps = 0; ps < TM / IP; ++ps) {
 #pragma unroll
@@ -443,6 +450,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm2_kernel(const GemmArgs p) 
           } else {
             *reinterpret_cast<f32x4_t*>(C + out_row(m) * p.ldc + n) = v;
           }
+          if (do_stats) *reinterpret_cast<f32x4_t*>(slice + row * RS + ch * 16) = v;
         }
       };
       if constexpr (RPRE) {
@@ -452,6 +460,33 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm2_kernel(const GemmArgs p) 
         for (int idx = lane; idx < IP * 16 * CPR; idx += 64) finish(idx, (f32x4_t){0.f, 0.f, 0.f, 0.f}, false);
       }
       __builtin_amdgcn_wave_barrier();
+      if (do_stats) {
+        const int row0 = mw + ps * IP * 16;
+        const int nrow = min(IP * 16, p.M - row0);          // rows of this pass inside the matrix
+#pragma unroll
+        for (int k = 0; k < NCR; ++k) {
+          const int c = lane + 64 * k;
+          if (c < WTN && nw + c < p.N) {
+            for (int row = 0; row < nrow; ++row) {
+              const float x = *reinterpret_cast<const float*>(slice + row * RS + c * 4);
+              cs[k] += x; cq[k] = __builtin_fmaf(x, x, cq[k]);
+            }
+          }
+        }
+        if (((ps + 1) * IP * 16) % 64 == 0 || ps == TM / IP - 1) {   // a 64-row block is complete
+          const int rb = row0 / 64;
+#pragma unroll
+          for (int k = 0; k < NCR; ++k) {
+            const int c = lane + 64 * k;
+            if (c < WTN && nw + c < p.N && rb * 64 < p.M) {
+              float* dst = p.colstats + ((size_t)rb * p.N + nw + c) * 2;
+              dst[0] = cs[k]; dst[1] = cq[k];
+            }
+            cs[k] = 0.f; cq[k] = 0.f;
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
     }
   } else if constexpr (EPI == 0) {
     constexpr int RS = WTN * 2 + 16;
@@ -462,6 +497,13 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm2_kernel(const GemmArgs p) 
     char* const slice = smem + wave * (IP * 16 * RS);
     const bf16_t* __restrict__ R = p.R ? (const bf16_t*)p.R + (size_t)batch * p.sR : nullptr;
     bf16_t* __restrict__ C = (bf16_t*)p.C + (size_t)batch * p.sC;
+    // column statistics (GemmArgs::colstats) of the ROUNDED values, as a GroupNorm reading the bf16 tensor would see them:
+    // a lane sums one pair of adjacent columns over the pass's rows
+    const bool do_stats = p.colstats != nullptr;
+    constexpr int NCP = (WTN / 2 + 63) / 64;               // column-pair rounds per lane
+    float cs[NCP][2], cq[NCP][2];
+#pragma unroll
+    for (int k = 0; k < NCP; ++k) { cs[k][0] = cs[k][1] = 0.f; cq[k][0] = cq[k][1] = 0.f; }
 #pragma unroll
     for (int ps = 0; ps < TM / IP; ++ps) {
 #pragma unroll
@@ -494,6 +536,32 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm2_kernel(const GemmArgs p) 
         const int m = mw + ps * IP * 16 + row, n = nw + ch * 8;
         const u32x4_t v = *reinterpret_cast<const u32x4_t*>(slice + row * RS + ch * 16);
         if (m < p.M && n < p.N) *reinterpret_cast<u32x4_t*>(C + out_row(m) * p.ldc + n) = v;
+      }
+      if (do_stats) {
+        const int row0 = mw + ps * IP * 16;
+        const int nrow = min(IP * 16, p.M - row0);
+#pragma unroll
+        for (int k = 0; k < NCP; ++k) {
+          const int c = 2 * (lane + 64 * k);                 // this lane's column pair
+          if (c < WTN && nw + c < p.N) {
+            for (int row = 0; row < nrow; ++row) {
+              const unsigned u = *reinterpret_cast<const unsigned*>(slice + row * RS + c * 2);
+              const float x0 = __builtin_bit_cast(float, u << 16), x1 = __builtin_bit_cast(float, u & 0xffff0000u);
+              cs[k][0] += x0; cq[k][0] = __builtin_fmaf(x0, x0, cq[k][0]);
+              cs[k][1] += x1; cq[k][1] = __builtin_fmaf(x1, x1, cq[k][1]);
+            }
+          }
+        }
+        if (((ps + 1) * IP * 16) % 64 == 0 || ps == TM / IP - 1) {
+          const int rb = row0 / 64;
+#pragma unroll
+          for (int k = 0; k < NCP; ++k) {
+            const int c = 2 * (lane + 64 * k);
+            if (c < WTN && nw + c < p.N && rb * 64 < p.M)
+              *reinterpret_cast<f32x4_t*>(p.colstats + ((size_t)rb * p.N + nw + c) * 2) = (f32x4_t){cs[k][0], cq[k][0], cs[k][1], cq[k][1]};
+            cs[k][0] = cs[k][1] = 0.f; cq[k][0] = cq[k][1] = 0.f;
+          }
+        }
       }
       __builtin_amdgcn_wave_barrier();
     }
@@ -566,6 +634,12 @@ template <typename T, int BM, int BN, int WGM, int WGN, int STAGES, bool CONV>
 static int launch2(GemmArgs& a, int batch, hipStream_t st) {
   a.tiles_m = (a.M + BM - 1) / BM;
   a.tiles_n = (a.N + BN - 1) / BN;
+  // column statistics ride the f32 / bf16 epilogues of an un-split, un-batched launch whose 64-row blocks are whole
+  // wave sub-tiles; everything else clears the request and the consumer computes its own statistics
+  if (a.colstats && (a.splits != 1 || batch != 1 || a.phase_up || a.out_f32 == 2 || a.act == ACT_GEGLU || (BM / WGM) % 64 != 0 ||
+                     (a.N % 2) != 0))
+    a.colstats = nullptr;
+  a.colstats_done = a.colstats != nullptr;
   // residual-prefetch kernel (EPI 1): f32 residual + f32 / hi|lo output, no split, on the tiles with the registers for it
   constexpr bool HAS_RPRE = WGM * WGN == 4 || (!CONV && BM == 128 && BN == 320);
   if constexpr (HAS_RPRE) {
@@ -599,7 +673,8 @@ int launch_splitk_reduce(const GemmArgs& a, hipStream_t st) {
 // kernel finishes the epilogue; that needs the caller's workspace.
 // mode: 0 = auto, 2 = any fitting tile however few workgroups, 3 = as 2 plus a 3-way K split.
 // Returns BM*1000+BN (0: use the 4-wave kernels of gemm_conv.hip) and *splits.
-int gemm2_choose_tile(int M, int N, int K, int batch, int mode, size_t ws_bytes, int* splits, int bke) {
+int gemm2_choose_tile(int M, int N, int K, int batch, int mode, size_t ws_bytes, int* splits, int bke, int* stages) {
+  if (stages) *stages = 2;
   auto blocks = [&](int bm, int bn) { return (long long)((M + bm - 1) / bm) * ((N + bn - 1) / bn) * batch; };
   const int nk = K / bke;
   const size_t slab = (size_t)M * N * sizeof(float);
@@ -612,10 +687,12 @@ int gemm2_choose_tile(int M, int N, int K, int batch, int mode, size_t ws_bytes,
   }
   extern int g_gemm_debug;
   if (g_gemm_debug >= 32) {   // experiment: forced tile / split (debug = 32 + 8*tile + splits)
-    static const int tiles[8] = {128160, 128320, 256256, 128128, 256320, 0, 0, 0};
+    static const int tiles[8] = {128160, 128320, 256256, 128128, 256320, 128160, 0, 0};   // index 5: 128x160 with a 3-stage ring
     const int s = (g_gemm_debug - 32) & 7;
     if (s >= 1 && s <= max_splits() && s <= nk) *splits = s;
-    return tiles[((g_gemm_debug - 32) >> 3) & 7];
+    const int ti = ((g_gemm_debug - 32) >> 3) & 7;
+    if (stages && ti == 5) *stages = 3;
+    return tiles[ti];
   }
   // bf16: the 4-wave 128x160 tile (two co-resident workgroups per CU overlap each other's prologue and
   // epilogue) beats the 8-wave 128x320 one by 3-9 % once it fills two rounds (>= 512 workgroups), except on
@@ -659,7 +736,8 @@ static int launch_gemm2_t(GemmArgs& a, int batch, bool conv, int mode, hipStream
   if ((a.ldr % 4) != 0 || (a.R && ((uintptr_t)a.R % 16) != 0)) return -1;
   if (sizeof(T) == 2 && !a.out_f32 && ((a.ldc % 8) != 0 || (a.sC % 8) != 0)) return -1;   // 16-byte row-segment stores
   if (sizeof(T) == 4 && ((a.ldc % 4) != 0 || (a.sC % 4) != 0)) return -1;
-  int tile = gemm2_choose_tile(a.M, a.N, a.K, batch, mode, a.ws ? a.ws_bytes : 0, &a.splits, 128 / (int)sizeof(T));
+  int stages = 2;
+  int tile = gemm2_choose_tile(a.M, a.N, a.K, batch, mode, a.ws ? a.ws_bytes : 0, &a.splits, 128 / (int)sizeof(T), &stages);
   if (a.act == ACT_GEGLU) {   // needs an even number of 16-column tiles per wave: 256x256 or 128x128
     if (sizeof(T) == 4 || conv || a.out_f32 || a.R || a.N % 256 != 0) return -1;
     extern int g_gemm_debug;
@@ -668,7 +746,11 @@ static int launch_gemm2_t(GemmArgs& a, int batch, bool conv, int mode, hipStream
   }
   switch (tile) {
     case 128128: return conv ? -1 : launch2<T, 128, 128, 2, 2, 2, false>(a, batch, st);
-    case 128160: return conv ? launch2<T, 128, 160, 2, 2, 2, true>(a, batch, st) : launch2<T, 128, 160, 2, 2, 2, false>(a, batch, st);
+    case 128160:
+      if constexpr (sizeof(T) == 2) {
+        if (stages == 3) return conv ? launch2<T, 128, 160, 2, 2, 3, true>(a, batch, st) : launch2<T, 128, 160, 2, 2, 3, false>(a, batch, st);
+      }
+      return conv ? launch2<T, 128, 160, 2, 2, 2, true>(a, batch, st) : launch2<T, 128, 160, 2, 2, 2, false>(a, batch, st);
     case 128320: return conv ? launch2<T, 128, 320, 2, 4, 2, true>(a, batch, st) : launch2<T, 128, 320, 2, 4, 2, false>(a, batch, st);
     case 256256: return conv ? launch2<T, 256, 256, 2, 4, 2, true>(a, batch, st) : launch2<T, 256, 256, 2, 4, 2, false>(a, batch, st);
     case 256320:

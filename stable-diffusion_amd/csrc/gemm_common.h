@@ -26,6 +26,12 @@ struct GemmArgs {
   int splits;
   float* ws;
   size_t ws_bytes;
+  // Column statistics for a GroupNorm that consumes C (gemm2.hip epilogues; null = off): per 64-row block rb and output
+  // column n, colstats[(rb * N + n) * 2 + {0, 1}] = sum and sum of squares of the stored C[rb*64 .. rb*64+63][n].
+  // The launcher clears the pointer for launches that cannot produce them (split-K, phase form, hi|lo / GeGLU output,
+  // batched, 4-wave register-staged kernels) and sets colstats_done = 1 when the kernel writes them.
+  float* colstats;
+  int colstats_done;
   int debug;   // timing experiments only (sdamd_set_gemm_impl(impl | debug << 8)): 1 = skip the DMA, 2 = skip the MFMAs
 };
 
@@ -33,7 +39,7 @@ struct GemmArgs {
 // gemm2.hip: 8-wave, LDS-DMA-staged kernels (bf16 and exact-f32 MFMA).  Returns -1 when no tile configuration of that
 // family fits the problem (the caller then uses the 4-wave register-staged kernels), 0 on launch.
 int launch_gemm2(GemmArgs& a, int dtype, int batch, bool conv, int mode, hipStream_t st);   // mode: g_gemm_impl
-int gemm2_choose_tile(int M, int N, int K, int batch, int mode, size_t ws_bytes, int* splits, int bke);
+int gemm2_choose_tile(int M, int N, int K, int batch, int mode, size_t ws_bytes, int* splits, int bke, int* stages = nullptr);
 
 // out = act(sum_s ws[s] + bias + residual) for a split-K launch (gemm2.hip)
 int launch_splitk_reduce(const GemmArgs& a, hipStream_t st);

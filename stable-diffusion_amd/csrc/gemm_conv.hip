@@ -447,8 +447,10 @@ static int check_common(const GemmArgs& a, int dtype, const char* what) {
 extern "C" int sdamd_gemm(const void* A, const void* W, void* C, const float* bias, const void* residual, int M, int N, int K,
                           int lda, int ldw, int ldc, int ldr, int batch, long long strideA, long long strideW,
                           long long strideC, long long strideR, int act, int dtype, int out_f32, void* ws,
-                          size_t ws_bytes, void* stream) {
+                          size_t ws_bytes, float* colstats, int* colstats_written, void* stream) {
+  if (colstats_written) *colstats_written = 0;
   GemmArgs a = {};
+  a.colstats = colstats;
   a.splits = 1; a.ws = (float*)ws; a.ws_bytes = ws_bytes; a.debug = g_gemm_debug;
   a.A = A; a.W = W; a.C = C; a.bias = bias; a.R = residual;
   a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldw = ldw; a.ldc = ldc; a.ldr = ldr;
@@ -463,7 +465,7 @@ extern "C" int sdamd_gemm(const void* A, const void* W, void* C, const float* bi
   hipStream_t st = (hipStream_t)stream;
   if (g_gemm_impl != 1) {
     const int r = launch_gemm2(a, dtype, batch, false, g_gemm_impl, st);
-    if (r >= 0) return r;
+    if (r >= 0) { if (colstats_written && r == 0) *colstats_written = a.colstats_done; return r; }
   }
   SD_CHECK(act != ACT_GEGLU, "gemm: the fused GeGLU epilogue needs bf16, N %% 256 == 0, no residual, bf16 output and the 8-wave kernels");
   SD_CHECK(out_f32 != 2, "gemm: the hi|lo output needs bf16 operands and a shape the LDS-DMA kernels take (sdamd_gemm_tile != 0)");
@@ -476,7 +478,8 @@ extern "C" int sdamd_gemm(const void* A, const void* W, void* C, const float* bi
 // upsample=1 reads the input through a nearest 2x upsample (diffusion.py:148-150, decoder.py:90-111).
 extern "C" int sdamd_conv3x3(const void* x, const void* w, void* y, const float* bias, const void* residual, int B, int H,
                              int Wd, int Cin, int Cout, int stride, int pad_mode, int upsample, int act, int dtype,
-                             int out_f32, void* ws, size_t ws_bytes, void* stream) {
+                             int out_f32, void* ws, size_t ws_bytes, float* colstats, int* colstats_written, void* stream) {
+  if (colstats_written) *colstats_written = 0;
   SD_CHECK(stride == 1 || stride == 2, "conv3x3: stride=%d", stride);
   SD_CHECK(pad_mode == 0 || pad_mode == 1, "conv3x3: pad_mode=%d", pad_mode);
   SD_CHECK(upsample >= 0 && upsample <= 2, "conv3x3: upsample=%d", upsample);
@@ -533,12 +536,13 @@ extern "C" int sdamd_conv3x3(const void* x, const void* w, void* y, const float*
   a.act = act; a.out_f32 = out_f32;
   a.splits = 1; a.ws = (float*)ws; a.ws_bytes = ws_bytes; a.debug = g_gemm_debug;
   a.H = H; a.Wd = Wd; a.Cin = Cin; a.Ho = Ho; a.Wo = Wo; a.stride = stride; a.pad = pad; a.ups = upsample;
+  a.colstats = colstats;
   if (int e = check_common(a, dtype, "conv3x3")) return e;
   const int bke = dtype == SDAMD_BF16 ? 64 : 32;
   SD_CHECK(Cin % bke == 0, "conv3x3: Cin=%d must be a multiple of %d (use the small-channel kernels)", Cin, bke);
   if (g_gemm_impl != 1) {
     const int r = launch_gemm2(a, dtype, 1, true, g_gemm_impl, st);
-    if (r >= 0) return r;
+    if (r >= 0) { if (colstats_written && r == 0) *colstats_written = a.colstats_done; return r; }
   }
   if (dtype == SDAMD_BF16) return pick_tile<bf16_t, true>(a, 1, st);
   return pick_tile<float, true>(a, 1, st);

@@ -386,6 +386,30 @@ __global__ __launch_bounds__(NT) void gn_group_kernel(const T* __restrict__ x, c
   }
 }
 
+// apply pass: ~4K vectors (64 KB) per block, but keep >= ~1024 blocks in flight; every block first finishes its sample's
+// statistics from the nblk_stats per-block partials in ws
+static int gn_launch_apply(const void* x, const void* x2, int C1, void* y, const float* gamma, const float* beta, const double* ws,
+                           int nblk_stats, int B, int HW, int C, float eps, int silu, int dtype, int out_dtype, hipStream_t st) {
+  const int V = dtype == SDAMD_BF16 ? 8 : 4;
+  int vpp = C / V;
+  long long total_vec = (long long)B * HW * vpp;
+  int vec_per_blk = 4096;
+  while (vec_per_blk > 512 && total_vec / vec_per_blk < 1024) vec_per_blk >>= 1;
+  int ppb2 = (vec_per_blk + vpp - 1) / vpp;
+  if (ppb2 < 1) ppb2 = 1;
+  int nblk2 = (HW + ppb2 - 1) / ppb2;
+  dim3 grid2(nblk2, B);
+  const size_t lds2 = (size_t)3 * C * sizeof(float);   // <= 30 KB at C = 2560
+  if (dtype == SDAMD_BF16)
+    gn_apply_kernel<bf16_t, bf16_t><<<grid2, 256, lds2, st>>>((const bf16_t*)x, (const bf16_t*)x2, C1, (bf16_t*)y, gamma, beta, ws, nblk_stats, eps, HW, C, silu, ppb2);
+  else if (out_dtype == SDAMD_BF16)
+    gn_apply_kernel<float, bf16_t><<<grid2, 256, lds2, st>>>((const float*)x, (const float*)x2, C1, (bf16_t*)y, gamma, beta, ws, nblk_stats, eps, HW, C, silu, ppb2);
+  else
+    gn_apply_kernel<float, float><<<grid2, 256, lds2, st>>>((const float*)x, (const float*)x2, C1, (float*)y, gamma, beta, ws, nblk_stats, eps, HW, C, silu, ppb2);
+  SD_LAUNCH_CHECK("gn_apply");
+  return 0;
+}
+
 static int groupnorm_impl(const void* x, const void* x2, int C1, void* y, const float* gamma, const float* beta, void* ws, int B,
                           int HW, int C, float eps, int silu, int dtype, int out_dtype, void* stream) {
   const int V = dtype == SDAMD_BF16 ? 8 : 4;
@@ -435,24 +459,57 @@ static int groupnorm_impl(const void* x, const void* x2, int C1, void* y, const 
 #undef GN_STATS_T
 #undef GN_STATS
   SD_LAUNCH_CHECK("gn_stats");
-  // apply: ~4K vectors (64 KB) per block, but keep >= ~1024 blocks in flight
-  int vpp = C / V;
-  long long total_vec = (long long)B * HW * vpp;
-  int vec_per_blk = 4096;
-  while (vec_per_blk > 512 && total_vec / vec_per_blk < 1024) vec_per_blk >>= 1;
-  int ppb2 = (vec_per_blk + vpp - 1) / vpp;
-  if (ppb2 < 1) ppb2 = 1;
-  int nblk2 = (HW + ppb2 - 1) / ppb2;
-  dim3 grid2(nblk2, B);
-  const size_t lds2 = (size_t)3 * C * sizeof(float);   // <= 30 KB at C = 2560
-  if (dtype == SDAMD_BF16)
-    gn_apply_kernel<bf16_t, bf16_t><<<grid2, 256, lds2, st>>>((const bf16_t*)x, (const bf16_t*)x2, C1, (bf16_t*)y, gamma, beta, (const double*)ws, nblk, eps, HW, C, silu, ppb2);
-  else if (out_dtype == SDAMD_BF16)
-    gn_apply_kernel<float, bf16_t><<<grid2, 256, lds2, st>>>((const float*)x, (const float*)x2, C1, (bf16_t*)y, gamma, beta, (const double*)ws, nblk, eps, HW, C, silu, ppb2);
-  else
-    gn_apply_kernel<float, float><<<grid2, 256, lds2, st>>>((const float*)x, (const float*)x2, C1, (float*)y, gamma, beta, (const double*)ws, nblk, eps, HW, C, silu, ppb2);
-  SD_LAUNCH_CHECK("gn_apply");
-  return 0;
+  return gn_launch_apply(x, x2, C1, y, gamma, beta, (const double*)ws, nblk, B, HW, C, eps, silu, dtype, out_dtype, st);
+}
+
+// GroupNorm statistics from the per-column partial sums a producing GEMM / conv epilogue left behind
+// (GemmArgs::colstats, gemm2.hip): s1 [B*HW/64][C1][2] (and s2 [..][C2][2] for the second source of a virtual concat)
+// hold sum and sum of squares of every channel over each 64-pixel block; sample n owns blocks [n*HW/64, (n+1)*HW/64).
+// One workgroup per sample folds them (f64, fixed order) into the [n][1 block][32 groups][2] layout gn_apply_kernel
+// finishes, so the statistics pass over the tensor itself (one full read of the f32 trunk) is not run at all.
+__global__ __launch_bounds__(256) void gn_finalize_pre_kernel(const float* __restrict__ s1, const float* __restrict__ s2, int C1,
+                                                              int C2, double* __restrict__ ws, int HW) {
+  // one workgroup per (group, sample): HW/64 blocks x C/32 channels partials, a few independent loads per thread
+  __shared__ double red[2][4];
+  const int g = blockIdx.x, n = blockIdx.y, t = threadIdx.x;
+  const int C = C1 + C2, cpg = C / 32, nrb = HW / 64;
+  double ss = 0.0, qq = 0.0;
+  for (int e = t; e < nrb * cpg; e += 256) {
+    const int rb = e / cpg, c = g * cpg + (e - rb * cpg);
+    const float* src = c < C1 ? s1 + ((size_t)(n * nrb + rb) * C1 + c) * 2 : s2 + ((size_t)(n * nrb + rb) * C2 + (c - C1)) * 2;
+    const f32x2_t v = *reinterpret_cast<const f32x2_t*>(src);
+    ss += (double)v[0]; qq += (double)v[1];
+  }
+  ss = wave_sum_d(ss); qq = wave_sum_d(qq);
+  if ((t & 63) == 0) { red[0][t >> 6] = ss; red[1][t >> 6] = qq; }
+  __syncthreads();
+  if (t == 0) {
+    double* dst = ws + ((size_t)n * 32 + g) * 2;
+    dst[0] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+    dst[1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+  }
+}
+
+extern "C" int sdamd_groupnorm_nhwc_pre(const void* x1, const void* x2, int C1, int C2, void* y, const float* gamma,
+                                        const float* beta, const float* stats1, const float* stats2, void* ws, int B, int HW,
+                                        float eps, int silu, int dtype, int out_dtype, void* stream) {
+  const int C = C1 + C2;
+  const int V = dtype == SDAMD_BF16 ? 8 : 4;
+  SD_CHECK(x1 && stats1 && C1 > 0 && (C2 == 0) == (x2 == nullptr) && (C2 == 0 || stats2), "groupnorm_pre: missing source or statistics");
+  SD_CHECK(HW % 64 == 0, "groupnorm_pre: HW=%d must be a multiple of the 64-row statistics block", HW);
+  SD_CHECK(B > 0 && C % 32 == 0 && C % V == 0 && (C2 == 0 || C1 % V == 0), "groupnorm_pre: unsupported shape B=%d C=%d+%d", B, C1, C2);
+  SD_CHECK((dtype == SDAMD_BF16 || dtype == SDAMD_F32) && (out_dtype == SDAMD_BF16 || out_dtype == SDAMD_F32) &&
+           !(dtype == SDAMD_BF16 && out_dtype == SDAMD_F32), "groupnorm_pre: unsupported dtypes in=%d out=%d", dtype, out_dtype);
+  {   // small maps: the one-launch kernel holds the whole group in registers, nothing to save
+    const int cpg = C / 32;
+    const long long items = (long long)HW * (cpg / 2);
+    if (cpg % 2 == 0 && items <= 512LL * GNG_MAXP && (!x2 || C1 % 2 == 0))
+      return groupnorm_impl(x1, x2, C1, y, gamma, beta, ws, B, HW, C, eps, silu, dtype, out_dtype, stream);
+  }
+  hipStream_t st = (hipStream_t)stream;
+  gn_finalize_pre_kernel<<<dim3(32, B), 256, 0, st>>>(stats1, stats2, C1, C2, (double*)ws, HW);
+  SD_LAUNCH_CHECK("gn_finalize_pre");
+  return gn_launch_apply(x1, x2, C1, y, gamma, beta, (const double*)ws, 1, B, HW, C, eps, silu, dtype, out_dtype, st);
 }
 
 extern "C" int sdamd_groupnorm_nhwc(const void* x, void* y, const float* gamma, const float* beta, void* ws, int B,

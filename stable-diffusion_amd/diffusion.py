@@ -52,11 +52,11 @@ class UNET_ResidualBlock(engine.HipModule):
             else:
                 x = ops.concat_channels(*x)
         h = engine.groupnorm(x, self.groupnorm_feature, silu=True, out_dtype=dt, x2=x2)
-        h = engine.conv3x3(h, self.conv_feature, bias=tbias)
+        h = engine.conv3x3(h, self.conv_feature, bias=tbias, want_stats=True)     # feeds groupnorm_merged
         h = engine.groupnorm(h, self.groupnorm_merged, silu=True)
         skip = x if isinstance(self.residual_layer, nn.Identity) else \
             engine.conv1x1(x, self.residual_layer, out_dtype=x.dtype, compute_dtype=dt, x2=x2)
-        return engine.conv3x3(h, self.conv_merged, residual=skip)
+        return engine.conv3x3(h, self.conv_merged, residual=skip, want_stats=True)   # feeds the next block's GroupNorm
 
     def forward(self, feature, time):
         tb = self.time_bias(ops.silu(time.float().contiguous()))
@@ -99,9 +99,9 @@ class UNET_AttentionBlock(engine.HipModule):
         g = engine.linear_geglu(engine.layernorm(t, self.layernorm_3, dt), self.linear_geglu_1)
         ts = engine.linear_hilo(g, self.linear_geglu_2, t) if dt == torch.bfloat16 else None
         if ts is not None:   # t is only ever read as conv_output's hi|lo operand: the GEMM epilogue writes that form
-            return engine.conv1x1_presplit(ts.view(B, H, W, 2 * C), self.conv_output, x)
+            return engine.conv1x1_presplit(ts.view(B, H, W, 2 * C), self.conv_output, x, want_stats=True)
         t = engine.linear(g, self.linear_geglu_2, residual=t)
-        return engine.conv1x1(t.view(B, H, W, C), self.conv_output, residual=x, compute_dtype=dt)
+        return engine.conv1x1(t.view(B, H, W, C), self.conv_output, residual=x, compute_dtype=dt, want_stats=True)
 
     def forward(self, x, prompt):
         kv = self.prompt_kv(prompt.contiguous())

@@ -12,10 +12,17 @@ import torch.distributed as dist
 
 
 def init_from_env(backend=None):
-    """Initialise from torchrun's RANK/WORLD_SIZE/LOCAL_RANK/MASTER_*; returns (rank, world, local)."""
+    """Initialise from torchrun's RANK/WORLD_SIZE/LOCAL_RANK/MASTER_*; returns (rank, world, local device index).
+
+    Rehearsal on a box with fewer GPUs than ranks (never the measured configuration): SDAMD_SHARE_GPU=1 maps rank r
+    to device r % device_count and SDAMD_DIST_BACKEND=gloo replaces RCCL (which refuses two ranks on one GPU); the
+    image all-gather then goes through host memory."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("SDAMD_SHARE_GPU") == "1" and torch.cuda.device_count() > 0:
+        local = local % torch.cuda.device_count()
+    backend = backend or os.environ.get("SDAMD_DIST_BACKEND")
     if world > 1 and not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
@@ -43,6 +50,8 @@ def all_gather_images(images, total=None):
         return images
     world = dist.get_world_size()
     images = images.contiguous()
+    if images.is_cuda and dist.get_backend() == "gloo":      # rehearsal only (see init_from_env): gather through the host
+        return all_gather_images(images.cpu(), total).to(images.device)
     sizes = [torch.zeros(1, dtype=torch.int64, device=images.device) for _ in range(world)]
     dist.all_gather(sizes, torch.tensor([images.shape[0]], dtype=torch.int64, device=images.device))
     sizes = [int(s) for s in sizes]
@@ -64,7 +73,7 @@ def all_gather_images(images, total=None):
 def max_over_ranks(value, device):
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return value
-    t = torch.tensor([value], dtype=torch.float64, device=device)
+    t = torch.tensor([value], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t)
 

@@ -138,14 +138,14 @@ def linear_hilo(x, lin, residual):
     return ops.gemm(x, linear_w(lin, x.dtype), bias_of(lin), residual, ops.ACT_NONE, out_hilo=True)
 
 
-def conv1x1_presplit(xs, conv, residual):
+def conv1x1_presplit(xs, conv, residual, want_stats=False):
     """conv1x1 of an operand that already is the hi|lo pair [..., 2C] (see conv1x1): f32 residual, f32 result."""
     w2 = packed(conv.weight, "c1x2", torch.bfloat16,
                 lambda w: w.reshape(w.shape[0], w.shape[1]).to(torch.bfloat16).repeat(1, 2).contiguous())
-    return ops.gemm(xs, w2, bias_of(conv), residual, ops.ACT_NONE, True, flops_k=conv.in_channels)
+    return ops.gemm(xs, w2, bias_of(conv), residual, ops.ACT_NONE, True, flops_k=conv.in_channels, want_stats=want_stats)
 
 
-def conv1x1(x, conv, residual=None, out_dtype=None, compute_dtype=None, x2=None):
+def conv1x1(x, conv, residual=None, out_dtype=None, compute_dtype=None, x2=None, want_stats=False):
     """x NHWC [B,H,W,C].  An f32 ``x`` under a bf16 compute dtype is the residual trunk itself:
     it goes through the MFMA as two bf16 terms (hi|lo) against [W|W] instead of being rounded.
     ``x2`` (that mode only): the operand is the channel concat [x | x2]."""
@@ -153,12 +153,14 @@ def conv1x1(x, conv, residual=None, out_dtype=None, compute_dtype=None, x2=None)
         w2 = packed(conv.weight, "c1x2", torch.bfloat16,
                     lambda w: w.reshape(w.shape[0], w.shape[1]).to(torch.bfloat16).repeat(1, 2).contiguous())
         xs = ops.split_hilo(x, x2)
-        return ops.gemm(xs, w2, bias_of(conv), residual, ops.ACT_NONE, _out_f32(xs, residual, out_dtype), flops_k=conv.in_channels)
+        return ops.gemm(xs, w2, bias_of(conv), residual, ops.ACT_NONE, _out_f32(xs, residual, out_dtype), flops_k=conv.in_channels,
+                        want_stats=want_stats)
     assert x2 is None
-    return ops.gemm(x, conv1x1_w(conv, x.dtype), bias_of(conv), residual, ops.ACT_NONE, _out_f32(x, residual, out_dtype))
+    return ops.gemm(x, conv1x1_w(conv, x.dtype), bias_of(conv), residual, ops.ACT_NONE, _out_f32(x, residual, out_dtype),
+                    want_stats=want_stats)
 
 
-def conv3x3(x, conv, residual=None, stride=1, pad_mode=0, upsample=False, bias=None, out_dtype=None):
+def conv3x3(x, conv, residual=None, stride=1, pad_mode=0, upsample=False, bias=None, out_dtype=None, want_stats=False):
     if upsample and residual is None and stride == 1 and pad_mode == 0 and \
             ops.gemm_supports_act(ops.ACT_GEGLU, torch.bfloat16, 256) and \
             (conv.out_channels % 160 == 0 or conv.out_channels % 256 == 0):
@@ -166,7 +168,7 @@ def conv3x3(x, conv, residual=None, stride=1, pad_mode=0, upsample=False, bias=N
         return ops.conv3x3(x, conv3x3_up_phase_w(conv, x.dtype, 1), bias_of(conv) if bias is None else bias, None, 1, 0, 2,
                            out_f32=_out_f32(x, residual, out_dtype))
     return ops.conv3x3(x, conv3x3_w(conv, x.dtype), bias_of(conv) if bias is None else bias, residual, stride,
-                       pad_mode, upsample, out_f32=_out_f32(x, residual, out_dtype))
+                       pad_mode, upsample, out_f32=_out_f32(x, residual, out_dtype), want_stats=want_stats)
 
 
 def conv3x3_up_phase_w(conv, dtype, dup):
@@ -198,13 +200,14 @@ def conv3x3_trunk(x, conv, compute_dtype, stride=1, upsample=False):
                                out_f32=True, flops_cin=conv.in_channels)
         w2 = packed(conv.weight, "c3x2", torch.bfloat16,
                     lambda w: w.permute(0, 2, 3, 1).to(torch.bfloat16).repeat(1, 1, 1, 2).reshape(w.shape[0], -1).contiguous())
-        return ops.conv3x3(ops.split_hilo(x), w2, bias_of(conv), None, stride, 0, upsample, out_f32=True, flops_cin=conv.in_channels)
+        return ops.conv3x3(ops.split_hilo(x), w2, bias_of(conv), None, stride, 0, upsample, out_f32=True, flops_cin=conv.in_channels,
+                           want_stats=True)
     if upsample and stride == 1 and ops.gemm_supports_act(ops.ACT_GEGLU, torch.bfloat16, 256) and \
             (conv.out_channels % 160 == 0 or conv.out_channels % 256 == 0) and x.shape[0] * x.shape[1] * x.shape[2] >= 256:
         # phase form, as conv3x3 above (below 256 low-resolution rows the f32 planner finds no split that fills the
         # chip and the gathered form on the 4-wave kernels is faster: 0.18 vs 0.81 ms at UNet batch 2, 8x8 -> 16x16)
         return ops.conv3x3(x, conv3x3_up_phase_w(conv, x.dtype, 1), bias_of(conv), None, 1, 0, 2)
-    return ops.conv3x3(x, conv3x3_w(conv, x.dtype), bias_of(conv), None, stride, 0, upsample)
+    return ops.conv3x3(x, conv3x3_w(conv, x.dtype), bias_of(conv), None, stride, 0, upsample, want_stats=True)
 
 
 def groupnorm(x, gn, silu, out_dtype=None, x2=None):

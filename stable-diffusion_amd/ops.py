@@ -6,6 +6,7 @@ launches are capturable into a hipGraph) and never falls back to torch eager mat
 
 Activation layout is NHWC / token-major: [B, H, W, C] or [B, S, C], float32 or bfloat16.
 """
+import ctypes
 import math
 
 import torch
@@ -222,15 +223,30 @@ def groupnorm(x, gamma, beta, eps, silu, out_dtype=None, x2=None):
     y = torch.empty(x.shape[:-1] + (C,), dtype=out_dtype, device=x.device)
     ws = _groupnorm_ws(B, x.device)
     L = _lib.lib()
-    if x2 is None:
+    # statistics left behind by the producing GEMM / conv epilogue (gemm / conv3x3 want_stats): no pass over x for them
+    st1 = getattr(x, "_sd_colstats", None)
+    st2 = None if x2 is None else getattr(x2, "_sd_colstats", None)
+    pre = USE_PRODUCER_STATS and st1 is not None and (x2 is None or st2 is not None) and HW % 64 == 0
+    if pre:
+        assert st1.shape == (B * HW // 64, C1, 2) and (st2 is None or st2.shape == (B * HW // 64, C2, 2))
+        call = lambda: _lib.check(L.sdamd_groupnorm_nhwc_pre(_p(x), _p(x2), C1, C2, _p(y), _p(gamma), _p(beta), _p(st1), _p(st2),
+                                                             _p(ws), B, HW, float(eps), int(silu), _code(x.dtype),
+                                                             _code(out_dtype), _stream()))
+    elif x2 is None:
         call = lambda: _lib.check(L.sdamd_groupnorm_nhwc(_p(x), _p(y), _p(gamma), _p(beta), _p(ws), B, HW, C, float(eps),
                                                          int(silu), _code(x.dtype), _code(out_dtype), _stream()))
     else:
         call = lambda: _lib.check(L.sdamd_groupnorm_nhwc_cat(_p(x), _p(x2), C1, C2, _p(y), _p(gamma), _p(beta), _p(ws), B, HW,
                                                              float(eps), int(silu), _code(x.dtype), _code(out_dtype), _stream()))
-    _timed(f"groupnorm_{_dt(x.dtype)}", B * HW * C * (x.element_size() + y.element_size()),   # 1 read + 1 write per element
+    _timed(f"groupnorm_{_dt(x.dtype)}" + ("_pre" if pre else ""), B * HW * C * (x.element_size() + y.element_size()),   # 1 read + 1 write per element
            call, f"B{B} HW{HW} C{C}" + (" cat" if x2 is not None else ""))
     return y
+
+
+USE_PRODUCER_STATS = True     # tests / A-B switch: False makes every GroupNorm compute its own statistics
+# Below ~8 M elements the statistics pass costs no more than the finalize launch that replaces it (measured at UNet
+# batch 16, experiments/ab_gnpre.py: 64x64x320 41.9 -> 28.1 us, 32x32x640 26.9 -> 19.4 us, 16x16x1280 15.9 -> 16.0 us)
+PRODUCER_STATS_MIN_ELEMS = 8 << 20
 
 
 def layernorm(x, gamma, beta, eps=1e-5, out_dtype=None):
@@ -421,12 +437,14 @@ def gemm_hilo_fused(M, N, K, dtype):
     return tile in (128160, 128320, 256256)      # the LDS-DMA tiles (gemm2.hip); the 4-wave ones have no such epilogue
 
 
-def gemm(a, w, bias=None, residual=None, act=ACT_NONE, out_f32=False, out_hilo=False, flops_k=None):
+def gemm(a, w, bias=None, residual=None, act=ACT_NONE, out_f32=False, out_hilo=False, flops_k=None, want_stats=False):
     """a [..., K] (last dim contiguous, uniform row stride), w [N, K] -> [..., N].  The result (and the
     residual, which must have the result's dtype) is f32 when ``out_f32``, else a's dtype.
     ``out_hilo``: f32 residual, result bf16 [..., 2N] = [bf16(v) | bf16(v - bf16(v))] (see split_hilo).
     ``flops_k``: the K of the reference's op when it differs from the executed one (hi|lo operands run 2K), for the
-    profiler's algorithmic-FLOP credit only."""
+    profiler's algorithmic-FLOP credit only.
+    ``want_stats``: the result feeds a GroupNorm: ask the epilogue for per-column partial statistics; when the launch
+    produced them they ride on the result as ``out._sd_colstats`` ([ceil(M/64), N, 2] f32) and ``groupnorm`` uses them."""
     _dev(a, w, bias, residual)
     K = a.shape[-1]
     N = w.shape[0]
@@ -457,14 +475,28 @@ def gemm(a, w, bias=None, residual=None, act=ACT_NONE, out_f32=False, out_hilo=F
         assert bias.dtype == torch.float32 and bias.numel() == N and bias.is_contiguous()
     ws = _gemm_workspace(a.device)
     nbytes = (M * K + N * K) * a.element_size() + out.numel() * out.element_size() + (0 if residual is None else residual.numel() * residual.element_size())
+    stats, wrote = _stats_request(want_stats and act != ACT_GEGLU and not out_hilo, M, N, a.device)
     _timed(lambda: f"gemm_{_dt(a.dtype)}_{_tile_tag(M, N, K, a.dtype, ws, 1, act, residual is not None and res_dtype == torch.float32)}",
            2.0 * M * N * (K if flops_k is None else flops_k),
            lambda: _lib.check(_lib.lib().sdamd_gemm(_p(a), _p(w), _p(out), _p(bias), _p(residual), M, N, K, lda, K, n_out, ldr, 1,
                                                     0, 0, 0, 0, int(act), _code(a.dtype), int(out_f32), _p(ws), ws.numel(),
-                                                    _stream())),
+                                                    _p(stats), wrote, _stream())),
            lambda: f"M{M} N{N} K{K}{' +res' if residual is not None else ''}{' hilo' if out_f32 == 2 else ' f32out' if out_f32 else ''}{' geglu' if act == ACT_GEGLU else ''}",
            nbytes)
+    _stats_attach(out, stats, wrote)
     return out
+
+
+def _stats_request(want, M, N, device):
+    """(stats buffer, ctypes flag) for a launch that should leave GroupNorm column statistics, or (None, None)."""
+    if not want or not USE_PRODUCER_STATS or M * N < PRODUCER_STATS_MIN_ELEMS:
+        return None, None
+    return torch.empty(((M + 63) // 64, N, 2), dtype=torch.float32, device=device), ctypes.byref(ctypes.c_int(0))
+
+
+def _stats_attach(out, stats, wrote):
+    if stats is not None and wrote._obj.value:
+        out._sd_colstats = stats
 
 
 def gemm_supports_act(act, dtype, N):
@@ -489,14 +521,15 @@ def bmm_nt(a, b, out_f32=False):
     assert b.shape[0] == Bt and b.shape[2] == K
     out = torch.empty((Bt, M, N), dtype=torch.float32 if out_f32 else a.dtype, device=a.device)
     _lib.check(_lib.lib().sdamd_gemm(_p(a), _p(b), _p(out), 0, 0, M, N, K, a.stride(1), b.stride(1), N, 0, Bt, a.stride(0),
-                                     b.stride(0), M * N, 0, ACT_NONE, _code(a.dtype), int(out_f32), 0, 0, _stream()))
+                                     b.stride(0), M * N, 0, ACT_NONE, _code(a.dtype), int(out_f32), 0, 0, 0, None, _stream()))
     return out
 
 
-def conv3x3(x, w, bias, residual=None, stride=1, pad_mode=0, upsample=False, act=ACT_NONE, out_f32=False, flops_cin=None):
+def conv3x3(x, w, bias, residual=None, stride=1, pad_mode=0, upsample=False, act=ACT_NONE, out_f32=False, flops_cin=None,
+            want_stats=False):
     """x [B,H,W,Cin] NHWC, w [Cout, 9*Cin] ([Cout][ky][kx][Cin]) -> [B,Ho,Wo,Cout].
     ``flops_cin``: the reference conv's Cin when the executed operand is its hi|lo split (2*Cin), for the profiler's
-    algorithmic-FLOP credit only."""
+    algorithmic-FLOP credit only.  ``want_stats``: as for ``gemm`` (the result feeds a GroupNorm)."""
     _dev(x, w, bias, residual)
     assert x.is_contiguous() and x.dim() == 4 and w.is_contiguous() and w.dtype == x.dtype
     B, H, W, Cin = x.shape
@@ -520,14 +553,16 @@ def conv3x3(x, w, bias, residual=None, stride=1, pad_mode=0, upsample=False, act
     M = B * Ho * Wo
     ws = _gemm_workspace(x.device)
     nbytes = (x.numel() + w.numel()) * x.element_size() + out.numel() * out.element_size() * (1 if residual is None else 2)
+    stats, wrote = _stats_request(want_stats and upsample != 2, M, Cout, x.device)
     # algorithmic FLOPs = the reference's nn.Conv2d (3x3 taps, un-split Cin), also for the 4/9-MAC phase form
     _timed(lambda: f"conv3x3_{_dt(x.dtype)}_{_tile_tag(M, Cout, 9 * Cin, x.dtype, ws, f32_residual=residual is not None and out.dtype == torch.float32, conv=True)}",
            2.0 * M * Cout * 9 * (Cin if flops_cin is None else flops_cin),
            lambda: _lib.check(_lib.lib().sdamd_conv3x3(_p(x), _p(w), _p(out), _p(bias), _p(residual), B, H, W, Cin, Cout, stride,
                                                        pad_mode, upsample, int(act), _code(x.dtype), int(out_f32),
-                                                       _p(ws), ws.numel(), _stream())),
+                                                       _p(ws), ws.numel(), _p(stats), wrote, _stream())),
            lambda: f"M{M} N{Cout} K{9 * Cin} s{stride}{' up' if upsample else ''}{' +res' if residual is not None else ''}{' f32out' if out_f32 else ''}",
            nbytes)
+    _stats_attach(out, stats, wrote)
     return out
 
 

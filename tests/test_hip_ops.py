@@ -471,6 +471,68 @@ def test_small_channel_convs(dtype):
         assert rel_l2(got.cpu(), want) < tol(dtype, 3e-6, 1e-5)
 
 
+# ------------------------------------------------------------------ GroupNorm statistics from the producer's epilogue
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,H,Cin,Cout,res", [(8, 32, 64, 320, True), (8, 32, 64, 320, False), (1, 64, 64, 640, True),
+                                               (16, 64, 64, 320, True), (2, 32, 320, 320, True)])   # last: split-K plan, no statistics
+def test_conv_epilogue_column_stats_feed_groupnorm(dtype, B, H, Cin, Cout, res):
+    """conv3x3(want_stats=True) leaves per-64-row-block column sums of the values it stored; groupnorm() then skips its
+    own statistics pass.  Checked: the partial sums themselves, and GroupNorm(+SiLU) == the two-pass kernel's result."""
+    x = q(rnd(f"cst.x.{Cin}.{H}", (B, H, H, Cin)), dtype).to(dtype).to(DEV)
+    w = q(rnd(f"cst.w.{Cin}.{Cout}", (Cout, 9 * Cin), 1.0 / math.sqrt(9 * Cin)), dtype).to(dtype).to(DEV)
+    b = rnd(f"cst.b.{Cout}", (Cout,)).to(DEV)
+    out_f32 = res or dtype == torch.float32
+    r = rnd(f"cst.r.{Cout}.{H}", (B, H, H, Cout), 2.0).to(DEV) if res else None
+    y = ops.conv3x3(x, w, b, r, 1, 0, False, out_f32=out_f32 and dtype != torch.float32, want_stats=True)
+    M = B * H * H
+    st = getattr(y, "_sd_colstats", None)
+    if st is None:
+        from sd_amd import _lib
+        t = _lib.lib().sdamd_gemm_tile(M, Cout, 9 * Cin, 1, 0 if dtype == torch.float32 else 1, ops.GEMM_WS_BYTES, 0)
+        assert t not in (128160, 128320, 256256, 256320), f"an un-split LDS-DMA launch (plan {t}) must produce the statistics"
+        # split-K (plan >= 1000000) or the register-staged kernels: no statistics, GroupNorm falls back to its own pass
+        gamma, beta = torch.ones(Cout, device=DEV), torch.zeros(Cout, device=DEV)
+        got = ops.groupnorm(y, gamma, beta, 1e-5, False, out_dtype=dtype)
+        ref = torch.nn.functional.group_norm(y.float().cpu().permute(0, 3, 1, 2), 32, eps=1e-5).permute(0, 2, 3, 1)
+        assert rel_l2(got.float().cpu(), ref) < tol(dtype, 2e-6, 4e-3)
+        return
+    assert tuple(st.shape) == ((M + 63) // 64, Cout, 2)
+    yf = y.float().reshape(M, Cout)
+    pad = (-M) % 64
+    yb = torch.nn.functional.pad(yf, (0, 0, 0, pad)).reshape(-1, 64, Cout).double()
+    assert rel_l2(st[..., 0].cpu(), yb.sum(1).float().cpu()) < 2e-6
+    assert rel_l2(st[..., 1].cpu(), (yb * yb).sum(1).float().cpu()) < 2e-6
+    if (H * H) % 64 == 0 and Cout % 32 == 0:
+        gamma, beta = (1.0 + 0.1 * rnd("cst.g", (Cout,))).to(DEV), (0.1 * rnd("cst.be", (Cout,))).to(DEV)
+        got = ops.groupnorm(y, gamma, beta, 1e-5, True, out_dtype=dtype)
+        plain = y.clone()                                   # no statistics attached: the two-pass kernels
+        want = ops.groupnorm(plain, gamma, beta, 1e-5, True, out_dtype=dtype)
+        assert rel_l2(got.float().cpu(), want.float().cpu()) < tol(dtype, 2e-6, 4e-3)
+
+
+def test_gemm_epilogue_column_stats_and_virtual_concat():
+    """The 1x1 conv_output GEMM (hi|lo operand, f32 residual) leaves statistics too; GroupNorm over the virtual concat
+    of two tensors that both carry statistics uses both sets."""
+    B, HW, C1, C2 = 8, 1024, 320, 640
+    a = rnd("gst.a", (B, HW, 2 * C1)).bfloat16().to(DEV)
+    w = (rnd("gst.w", (C1, 2 * C1)) * (2 * C1) ** -0.5).bfloat16().to(DEV)
+    r = rnd("gst.r", (B, HW, C1), 2.0).to(DEV)
+    y1 = ops.gemm(a, w, None, r, out_f32=True, want_stats=True)
+    a2 = rnd("gst.a2", (B, HW, 640)).bfloat16().to(DEV)
+    w2 = (rnd("gst.w2", (C2, 640)) * 640 ** -0.5).bfloat16().to(DEV)
+    y2 = ops.gemm(a2, w2, None, rnd("gst.r2", (B, HW, C2), 2.0).to(DEV), out_f32=True, want_stats=True)
+    assert getattr(y1, "_sd_colstats", None) is not None and getattr(y2, "_sd_colstats", None) is not None
+    assert rel_l2(y1._sd_colstats[..., 0].cpu(), y1.reshape(-1, 64, C1).double().sum(1).float().cpu()) < 2e-6
+    C = C1 + C2
+    gamma, beta = (1.0 + 0.1 * rnd("gst.g", (C,))).to(DEV), (0.1 * rnd("gst.be", (C,))).to(DEV)
+    got = ops.groupnorm(y1, gamma, beta, 1e-5, True, out_dtype=torch.bfloat16, x2=y2)
+    want = ops.groupnorm(y1.clone(), gamma, beta, 1e-5, True, out_dtype=torch.bfloat16, x2=y2.clone())
+    assert rel_l2(got.float().cpu(), want.float().cpu()) < 4e-3
+    ref = torch.nn.functional.silu(torch.nn.functional.group_norm(
+        torch.cat([y1, y2], -1).cpu().permute(0, 2, 1).reshape(B, C, HW, 1), 32, gamma.cpu(), beta.cpu(), 1e-5)).reshape(B, C, HW).permute(0, 2, 1)
+    assert rel_l2(got.float().cpu(), ref) < 4e-3
+
+
 # ------------------------------------------------------------------ flash attention
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("B,H,d,Sq,Skv,causal", [
