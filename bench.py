@@ -33,6 +33,11 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+import torch  # noqa: E402  (importing torch / sd_amd does not initialise the GPU; main() spawns ranks before any GPU call)
+
+import sd_amd  # noqa: E402,F401
+from sd_amd import clip, decoder, diffusion, distributed, engine, ops, pipeline, synth  # noqa: E402
+
 PEAK = {"bf16": 2500.0, "f32": 157.3, "hbm": 8000.0}  # MI355X_MICROARCH.md: dense TFLOP/s, GB/s
 GFLOP_PER_IMAGE = 82866.0                              # 50 x 1606.5 + 2514.5 + 26.6
 PMC_TRAFFIC_FILES = ("r02_pmc_traffic.json", "r01_pmc_traffic.json")   # newest first
@@ -45,7 +50,7 @@ def kernel_symbol(kind):
         bm, bn = parts[2].split("x")
         conv = "true" if parts[0] == "conv3x3" else "false"
         t = "unsigned short" if parts[1] == "bf16" else "float"
-        wg = {"128x320": "2, 4, 2", "128x160": "2, 2, 2", "256x256": "2, 4, 2", "256x320": "4, 2, 2"}.get(parts[2])
+        wg = {"128x320": "2, 4, 2", "128x160": "2, 2, 2", "64x160": "2, 2, 2", "256x256": "2, 4, 2", "256x320": "4, 2, 2"}.get(parts[2])
         if wg is not None:      # LDS-DMA family (gemm2.hip); last argument: 1 = residual-prefetch, 2 = GeGLU-only epilogue
             return f"gemm2_kernel<{t}, {bm}, {bn}, {wg}, {conv}, {1 if 'rp' in parts[3:] else 2 if 'geglu' in parts[3:] else 0}>"
         return f"gemm_kernel<{t}, {bm}, {bn}, {conv}>"
@@ -99,177 +104,176 @@ def main():
     run(args)
 
 
+
+def build_models(device, dtype, keep_cpu):
+    torch.set_grad_enabled(False)
+    specs = (("clip", clip.CLIP), ("decoder", decoder.VAE_Decoder), ("diffusion", diffusion.Diffusion))
+    models, cpu_sd = {}, {}
+    for name, cls in specs:
+        m = synth.load_hashed(cls(), name + ".")
+        if keep_cpu:
+            cpu_sd[name] = {k: v.clone() for k, v in m.state_dict().items()}
+        # text encoder on the f32 kernels, as pipeline.generate runs it (see pipeline.py)
+        models[name] = engine.set_compute_dtype(m.to(device), torch.float32 if name == "clip" else dtype)
+    return models, cpu_sd
+
+class Txt2ImgJob:
+    """Everything of generate() that can be prepared ahead, for a fixed batch of prompts/seeds."""
+
+    def __init__(self, models, first_image, batch, denoise_steps, cfg_scale, device, use_graph=True):
+        self.models, self.B = models, batch
+        ids = [synth.synthetic_token_ids(first_image + i) for i in range(batch)]
+        self.pos = torch.tensor(ids, dtype=torch.long, device=device)
+        self.neg = torch.tensor([synth.EMPTY_PROMPT_IDS] * batch, dtype=torch.long, device=device)
+        seeds = [42 + first_image + i for i in range(batch)]
+        ts, coef, noise, lat = pipeline.prepare_latents(seeds, pipeline.DDPMSampler, denoise_steps, (1, 4, 64, 64), device)
+        self.latents0 = lat.float().contiguous()
+        ctx = pipeline.encode_prompts(models["clip"], self.pos, self.neg)
+        self.loop = pipeline.DenoiseLoop(models["diffusion"], ctx, ts, coef, noise, self.latents0, cfg_scale, True, use_graph)
+
+    def step(self):
+        ctx = pipeline.encode_prompts(self.models["clip"], self.pos, self.neg)
+        self.loop.set_context(ctx)
+        self.loop.reset(self.latents0)
+        final = self.loop.run()
+        images = pipeline.decode_to_uint8(self.models["decoder"], final)
+        return distributed.all_gather_images(images)
+
+def unet_step_ms(loop, latents0, iters=20, warm=3):
+    """one captured Diffusion forward + CFG + step; median of >= 20 after 3 warm-ups, HIP events."""
+    iters = max(1, min(iters, loop.n_steps - warm)) if loop.n_steps > warm else 1
+    warm = min(warm, max(0, loop.n_steps - iters))
+    loop.reset(latents0)
+    for _ in range(warm):
+        loop.step()
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(iters + 1)]
+    evs[0].record()
+    for i in range(iters):
+        loop.step()
+        evs[i + 1].record()
+    torch.cuda.synchronize()
+    times = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(iters))
+    loop.reset(latents0)
+    return times[len(times) // 2]
+
+def roofline_leg(models, args, device):
+    """One eager pass of the same step with HIP-event pairs around every heavy launch."""
+    job = Txt2ImgJob(models, 0, args.batch, args.denoise_steps, 7.5, device, use_graph=False)
+    job.step()                                     # warm (weights already packed)
+    torch.cuda.synchronize()
+    ops.PROFILER = ops.LaunchTimer()
+    try:
+        job.step()
+        summ = ops.PROFILER.summary()
+    finally:
+        ops.PROFILER = None
+    is_mfma = lambda kind: kind.split("_")[0] in ("conv3x3", "gemm", "attention")
+    rows = []
+    for kind, v in summ.items():
+        mfma = is_mfma(kind)
+        dt = "bf16" if "_bf16" in kind else "f32"
+        rate = v["work"] / (v["ms"] * 1e-3) / (1e12 if mfma else 1e9)
+        rows.append({"kernel": kind, "launches": v["launches"], "total_ms": round(v["ms"], 3),
+                     "avg_us": round(1e3 * v["ms"] / v["launches"], 2), "bound": "mfma" if mfma else "hbm",
+                     "achieved": round(rate, 2), "unit": "TFLOP/s" if mfma else "GB/s",
+                     "frac": round(rate / (PEAK[dt] if mfma else PEAK["hbm"]), 4)})
+    rows.sort(key=lambda r: -r["total_ms"])
+    # the roofline object is per kernel SYMBOL (what a rocprofv3 trace shows): split-K variants and all
+    # problem shapes of one template instantiation are one entry
+    by_sym = {}
+    for kind, v in summ.items():
+        e = by_sym.setdefault(kernel_symbol(kind), {"ms": 0.0, "work": 0.0, "bytes": 0.0, "launches": 0, "kinds": []})
+        e["ms"] += v["ms"]; e["work"] += v["work"]; e["bytes"] += v["bytes"]; e["launches"] += v["launches"]; e["kinds"].append(kind)
+    sym, top = max(by_sym.items(), key=lambda kv: kv[1]["ms"])
+    mfma = is_mfma(top["kinds"][0])
+    dt = "bf16" if "_bf16" in top["kinds"][0] else "f32"
+    peak = PEAK[dt] if mfma else PEAK["hbm"]
+    rate = top["work"] / (top["ms"] * 1e-3) / (1e12 if mfma else 1e9)
+    traffic, traffic_src = pmc_traffic(sym)
+    roof = {"kernel": sym, "labels": sorted(top["kinds"]), "bound": "mfma" if mfma else "hbm",
+            "achieved": round(rate, 2), "peak": peak, "unit": "TFLOP/s" if mfma else "GB/s", "frac": round(rate / peak, 4),
+            "traffic": traffic, "traffic_source": traffic_src, "launches": top["launches"],
+            "avg_launch_us": round(1e3 * top["ms"] / top["launches"], 2),
+            "algorithmic_work_per_launch": round(top["work"] / top["launches"] / (1e9 if mfma else 1e6), 3),
+            "work_unit": "GFLOP" if mfma else "MB",
+            "algorithmic_bytes_per_launch": round(top["bytes"] / top["launches"]),
+            "note": "dominant kernel symbol of one bench step (most summed time over all its launches): mean algorithmic FLOPs "
+                    "per launch / mean launch duration (HIP events on the launch stream, one extra eager pass; a split-K launch "
+                    "includes its reduce kernel).  FLOPs are the reference op's 2*M*N*K (SURVEY.md §8d): the hi|lo operand "
+                    "doubling and the 4/9-MAC upsample form earn no credit.  algorithmic_bytes = operands + weights + result "
+                    "(+ residual), each once.  traffic = mean fabric bytes per launch from profiles/<traffic_source> (rocprofv3 "
+                    "--pmc FETCH_SIZE / WRITE_SIZE passes over eager UNet steps, FETCH_SIZE doubled as MI355X_MICROARCH.md "
+                    "prescribes for gfx950), null if not collected for this symbol"}
+    return roof, rows
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+def cpu_baseline_leg(cpu_sd):
+    """BASELINE config 1 (txt2img b1, 50-step DDPM, CFG 7.5, fp32, CPU) on the CPU oracle, bounded: the first 2 of
+    the 50 UNet steps (UNet batch 2, sampler step included), 1 VAE decode, the 2 CLIP encodes -- each stage timed,
+    then summed to the full run, once as this framework runs it (final decode only) and once as the reference runs
+    it (preview decode after every step, pipeline.py:156-164)."""
+    from oracle import sd_oracle as O
+    threads = torch.get_num_threads()
+    toks = torch.tensor([synth.synthetic_token_ids(0), synth.EMPTY_PROMPT_IDS])
+    t0 = time.perf_counter()
+    ctx = O.clip_forward(cpu_sd["clip"], toks)
+    t_clip2 = time.perf_counter() - t0
+    samp = O.DDPMSampler(torch.Generator().manual_seed(42))
+    samp.set_steps(50)
+    lat = torch.randn((1, 4, 64, 64), generator=samp.generator)
+    t_unet = []
+    for t in samp.timesteps[:2]:
+        t0 = time.perf_counter()
+        out = O.diffusion_forward(cpu_sd["diffusion"], lat.repeat(2, 1, 1, 1), ctx, O.get_time_embedding(int(t)))
+        eps = 7.5 * (out[0:1] - out[1:2]) + out[1:2]
+        lat = samp.step(int(t), lat, eps)
+        t_unet.append(time.perf_counter() - t0)
+    t_unet = sum(t_unet) / len(t_unet)
+    t0 = time.perf_counter()
+    O.vae_decode(cpu_sd["decoder"], lat)
+    t_dec = time.perf_counter() - t0
+    per_image = 50 * t_unet + t_dec + t_clip2
+    per_image_preview = 50 * (t_unet + t_dec) + t_clip2
+    return {"value": round(1.0 / per_image, 6), "unit": "images/s", "cores": threads, "kind": "port",
+            "cpu_model": cpu_model(), "host_cpus": os.cpu_count(),
+            "value_with_preview_decode": round(1.0 / per_image_preview, 6),
+            "sample": f"BASELINE config 1 bounded: steps 1-2 of 50 (UNet b2@64x64 fp32 + CFG + DDPM step, mean {t_unet:.2f}s) + 1 VAE "
+                      f"decode ({t_dec:.2f}s) + 2 CLIP encodes ({t_clip2:.2f}s) on {threads} threads; value = 1 / (50 steps + final "
+                      f"decode + CLIP) = {per_image:.0f}s per image; value_with_preview_decode = the reference's loop with its "
+                      f"per-step preview decode = {per_image_preview:.0f}s per image",
+            "unet_step_s": round(t_unet, 3), "vae_decode_s": round(t_dec, 3), "clip2_s": round(t_clip2, 3)}
+
+def generate_wall_leg(models, args, device, world, rank):
+    """wall(pipeline.generate(...)) for the same batch, as SURVEY.md §8d defines images/sec: tokenise, CLIP, host
+    noise draw (CPU mt19937, the reference's stream) + upload, 50 steps, decode, uint8, device->host copy of the
+    images.  Graph capture happens in the first (untimed) call and is re-used (pipeline._denoise_loop)."""
+    tok = synth.SyntheticTokenizer()
+    prompts = [f"synthetic:{rank * args.batch + i}" for i in range(args.batch)]
+    kw = dict(models=models, seed=42 + rank * args.batch, device=str(device), sampler="ddpm", steps=args.denoise_steps,
+              cfg_scale=7.5, tokenizer=tok, compute_dtype=torch.bfloat16)
+    pipeline.generate(prompts, "", **kw)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n = 2
+    for _ in range(n):
+        imgs = pipeline.generate(prompts, "", **kw)
+    dt = (time.perf_counter() - t0) / n
+    assert imgs.shape == (args.batch, 512, 512, 3)
+    pipeline.clear_loop_cache()
+    return dt
+
+
+
 # ---------------------------------------------------------------------------------------------------------------
 def run(args):
-    import torch
-    import sd_amd  # noqa: F401
-    from sd_amd import clip, decoder, diffusion, distributed, engine, ops, pipeline, synth
-
-    def build_models(device, dtype, keep_cpu):
-        torch.set_grad_enabled(False)
-        specs = (("clip", clip.CLIP), ("decoder", decoder.VAE_Decoder), ("diffusion", diffusion.Diffusion))
-        models, cpu_sd = {}, {}
-        for name, cls in specs:
-            m = synth.load_hashed(cls(), name + ".")
-            if keep_cpu:
-                cpu_sd[name] = {k: v.clone() for k, v in m.state_dict().items()}
-            # text encoder on the f32 kernels, as pipeline.generate runs it (see pipeline.py)
-            models[name] = engine.set_compute_dtype(m.to(device), torch.float32 if name == "clip" else dtype)
-        return models, cpu_sd
-
-    class Txt2ImgJob:
-        """Everything of generate() that can be prepared ahead, for a fixed batch of prompts/seeds."""
-
-        def __init__(self, models, first_image, batch, denoise_steps, cfg_scale, device, use_graph=True):
-            self.models, self.B = models, batch
-            ids = [synth.synthetic_token_ids(first_image + i) for i in range(batch)]
-            self.pos = torch.tensor(ids, dtype=torch.long, device=device)
-            self.neg = torch.tensor([synth.EMPTY_PROMPT_IDS] * batch, dtype=torch.long, device=device)
-            seeds = [42 + first_image + i for i in range(batch)]
-            ts, coef, noise, lat = pipeline.prepare_latents(seeds, pipeline.DDPMSampler, denoise_steps, (1, 4, 64, 64), device)
-            self.latents0 = lat.float().contiguous()
-            ctx = pipeline.encode_prompts(models["clip"], self.pos, self.neg)
-            self.loop = pipeline.DenoiseLoop(models["diffusion"], ctx, ts, coef, noise, self.latents0, cfg_scale, True, use_graph)
-
-        def step(self):
-            ctx = pipeline.encode_prompts(self.models["clip"], self.pos, self.neg)
-            self.loop.set_context(ctx)
-            self.loop.reset(self.latents0)
-            final = self.loop.run()
-            images = pipeline.decode_to_uint8(self.models["decoder"], final)
-            return distributed.all_gather_images(images)
-
-    def unet_step_ms(loop, latents0, iters=20, warm=3):
-        """one captured Diffusion forward + CFG + step; median of >= 20 after 3 warm-ups, HIP events."""
-        iters = max(1, min(iters, loop.n_steps - warm)) if loop.n_steps > warm else 1
-        warm = min(warm, max(0, loop.n_steps - iters))
-        loop.reset(latents0)
-        for _ in range(warm):
-            loop.step()
-        evs = [torch.cuda.Event(enable_timing=True) for _ in range(iters + 1)]
-        evs[0].record()
-        for i in range(iters):
-            loop.step()
-            evs[i + 1].record()
-        torch.cuda.synchronize()
-        times = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(iters))
-        loop.reset(latents0)
-        return times[len(times) // 2]
-
-    def roofline_leg(models, device):
-        """One eager pass of the same step with HIP-event pairs around every heavy launch."""
-        job = Txt2ImgJob(models, 0, args.batch, args.denoise_steps, 7.5, device, use_graph=False)
-        job.step()                                     # warm (weights already packed)
-        torch.cuda.synchronize()
-        ops.PROFILER = ops.LaunchTimer()
-        try:
-            job.step()
-            summ = ops.PROFILER.summary()
-        finally:
-            ops.PROFILER = None
-        is_mfma = lambda kind: kind.split("_")[0] in ("conv3x3", "gemm", "attention")
-        rows = []
-        for kind, v in summ.items():
-            mfma = is_mfma(kind)
-            dt = "bf16" if "_bf16" in kind else "f32"
-            rate = v["work"] / (v["ms"] * 1e-3) / (1e12 if mfma else 1e9)
-            rows.append({"kernel": kind, "launches": v["launches"], "total_ms": round(v["ms"], 3),
-                         "avg_us": round(1e3 * v["ms"] / v["launches"], 2), "bound": "mfma" if mfma else "hbm",
-                         "achieved": round(rate, 2), "unit": "TFLOP/s" if mfma else "GB/s",
-                         "frac": round(rate / (PEAK[dt] if mfma else PEAK["hbm"]), 4)})
-        rows.sort(key=lambda r: -r["total_ms"])
-        # the roofline object is per kernel SYMBOL (what a rocprofv3 trace shows): split-K variants and all
-        # problem shapes of one template instantiation are one entry
-        by_sym = {}
-        for kind, v in summ.items():
-            e = by_sym.setdefault(kernel_symbol(kind), {"ms": 0.0, "work": 0.0, "bytes": 0.0, "launches": 0, "kinds": []})
-            e["ms"] += v["ms"]; e["work"] += v["work"]; e["bytes"] += v["bytes"]; e["launches"] += v["launches"]; e["kinds"].append(kind)
-        sym, top = max(by_sym.items(), key=lambda kv: kv[1]["ms"])
-        mfma = is_mfma(top["kinds"][0])
-        dt = "bf16" if "_bf16" in top["kinds"][0] else "f32"
-        peak = PEAK[dt] if mfma else PEAK["hbm"]
-        rate = top["work"] / (top["ms"] * 1e-3) / (1e12 if mfma else 1e9)
-        traffic, traffic_src = pmc_traffic(sym)
-        roof = {"kernel": sym, "labels": sorted(top["kinds"]), "bound": "mfma" if mfma else "hbm",
-                "achieved": round(rate, 2), "peak": peak, "unit": "TFLOP/s" if mfma else "GB/s", "frac": round(rate / peak, 4),
-                "traffic": traffic, "traffic_source": traffic_src, "launches": top["launches"],
-                "avg_launch_us": round(1e3 * top["ms"] / top["launches"], 2),
-                "algorithmic_work_per_launch": round(top["work"] / top["launches"] / (1e9 if mfma else 1e6), 3),
-                "work_unit": "GFLOP" if mfma else "MB",
-                "algorithmic_bytes_per_launch": round(top["bytes"] / top["launches"]),
-                "note": "dominant kernel symbol of one bench step (most summed time over all its launches): mean algorithmic FLOPs "
-                        "per launch / mean launch duration (HIP events on the launch stream, one extra eager pass; a split-K launch "
-                        "includes its reduce kernel).  FLOPs are the reference op's 2*M*N*K (SURVEY.md §8d): the hi|lo operand "
-                        "doubling and the 4/9-MAC upsample form earn no credit.  algorithmic_bytes = operands + weights + result "
-                        "(+ residual), each once.  traffic = mean fabric bytes per launch from profiles/<traffic_source> (rocprofv3 "
-                        "--pmc FETCH_SIZE / WRITE_SIZE passes over eager UNet steps, FETCH_SIZE doubled as MI355X_MICROARCH.md "
-                        "prescribes for gfx950), null if not collected for this symbol"}
-        return roof, rows
-
-    def cpu_model():
-        try:
-            for line in open("/proc/cpuinfo"):
-                if line.startswith("model name"):
-                    return line.split(":", 1)[1].strip()
-        except OSError:
-            pass
-        return "unknown"
-
-    def cpu_baseline_leg(cpu_sd):
-        """BASELINE config 1 (txt2img b1, 50-step DDPM, CFG 7.5, fp32, CPU) on the CPU oracle, bounded: the first 2 of
-        the 50 UNet steps (UNet batch 2, sampler step included), 1 VAE decode, the 2 CLIP encodes -- each stage timed,
-        then summed to the full run, once as this framework runs it (final decode only) and once as the reference runs
-        it (preview decode after every step, pipeline.py:156-164)."""
-        from oracle import sd_oracle as O
-        threads = torch.get_num_threads()
-        toks = torch.tensor([synth.synthetic_token_ids(0), synth.EMPTY_PROMPT_IDS])
-        t0 = time.perf_counter()
-        ctx = O.clip_forward(cpu_sd["clip"], toks)
-        t_clip2 = time.perf_counter() - t0
-        samp = O.DDPMSampler(torch.Generator().manual_seed(42))
-        samp.set_steps(50)
-        lat = torch.randn((1, 4, 64, 64), generator=samp.generator)
-        t_unet = []
-        for t in samp.timesteps[:2]:
-            t0 = time.perf_counter()
-            out = O.diffusion_forward(cpu_sd["diffusion"], lat.repeat(2, 1, 1, 1), ctx, O.get_time_embedding(int(t)))
-            eps = 7.5 * (out[0:1] - out[1:2]) + out[1:2]
-            lat = samp.step(int(t), lat, eps)
-            t_unet.append(time.perf_counter() - t0)
-        t_unet = sum(t_unet) / len(t_unet)
-        t0 = time.perf_counter()
-        O.vae_decode(cpu_sd["decoder"], lat)
-        t_dec = time.perf_counter() - t0
-        per_image = 50 * t_unet + t_dec + t_clip2
-        per_image_preview = 50 * (t_unet + t_dec) + t_clip2
-        return {"value": round(1.0 / per_image, 6), "unit": "images/s", "cores": threads, "kind": "port",
-                "cpu_model": cpu_model(), "host_cpus": os.cpu_count(),
-                "value_with_preview_decode": round(1.0 / per_image_preview, 6),
-                "sample": f"BASELINE config 1 bounded: steps 1-2 of 50 (UNet b2@64x64 fp32 + CFG + DDPM step, mean {t_unet:.2f}s) + 1 VAE "
-                          f"decode ({t_dec:.2f}s) + 2 CLIP encodes ({t_clip2:.2f}s) on {threads} threads; value = 1 / (50 steps + final "
-                          f"decode + CLIP) = {per_image:.0f}s per image; value_with_preview_decode = the reference's loop with its "
-                          f"per-step preview decode = {per_image_preview:.0f}s per image",
-                "unet_step_s": round(t_unet, 3), "vae_decode_s": round(t_dec, 3), "clip2_s": round(t_clip2, 3)}
-
-    def generate_wall_leg(models, device, world, rank):
-        """wall(pipeline.generate(...)) for the same batch, as SURVEY.md §8d defines images/sec: tokenise, CLIP, host
-        noise draw (CPU mt19937, the reference's stream) + upload, 50 steps, decode, uint8, device->host copy of the
-        images.  Graph capture happens in the first (untimed) call and is re-used (pipeline._denoise_loop)."""
-        tok = synth.SyntheticTokenizer()
-        prompts = [f"synthetic:{rank * args.batch + i}" for i in range(args.batch)]
-        kw = dict(models=models, seed=42 + rank * args.batch, device=str(device), sampler="ddpm", steps=args.denoise_steps,
-                  cfg_scale=7.5, tokenizer=tok, compute_dtype=torch.bfloat16)
-        pipeline.generate(prompts, "", **kw)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        n = 2
-        for _ in range(n):
-            imgs = pipeline.generate(prompts, "", **kw)
-        dt = (time.perf_counter() - t0) / n
-        assert imgs.shape == (args.batch, 512, 512, 3)
-        pipeline.clear_loop_cache()
-        return dt
-
     rank, world, local = distributed.init_from_env()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
@@ -293,7 +297,7 @@ def run(args):
 
     gen_wall = None
     if not args.skip_generate_wall:
-        gen_wall = distributed.max_over_ranks(generate_wall_leg(models, device, world, rank), device)
+        gen_wall = distributed.max_over_ranks(generate_wall_leg(models, args, device, world, rank), device)
     if rank != 0:
         return
     ms_per_step = 1e3 * elapsed / args.steps
@@ -302,7 +306,8 @@ def run(args):
         "metric": "images/sec @512x512 50-step DDPM+CFG", "value": round(value, 4), "unit": "images/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 2),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-        "config": {"workload": "BASELINE config 3: txt2img 512x512, 50-step DDPM, CFG 7.5, bf16, batch 8 per GPU, "
+        "config": {"workload": ("BASELINE config 3: " if (args.batch, args.denoise_steps) == (8, 50) else "NON-STANDARD rehearsal of config 3: ") +
+                               f"txt2img 512x512, {args.denoise_steps}-step DDPM, CFG 7.5, bf16, batch {args.batch} per GPU, "
                                "incl. CLIP encode + final VAE decode + uint8 (+ all-gather when N>1); hash-init SD-v1.5 weights, "
                                "synthetic token ids",
                    "global_batch": world * args.batch, "per_gpu_batch": args.batch, "denoise_steps": args.denoise_steps,
@@ -319,7 +324,7 @@ def run(args):
                                        "includes tokenising, the host noise draw (50 x B x 16384 normals from the CPU generator) and "
                                        "its upload, CLIP, 50 steps, VAE decode, uint8 and the device->host image copy; no all-gather")
     if not args.skip_roofline:
-        roof, rows = roofline_leg(models, device)
+        roof, rows = roofline_leg(models, args, device)
         result["roofline"] = roof
         extra["kernel_breakdown"] = rows[:12]
         # north_star: achieved HBM GB/s of the fused norm and sampler kernels against the 8 TB/s peak

@@ -1,14 +1,23 @@
 """Same-process A/B of one captured UNet step (bf16, UNet batch 2*B) under a Python-level switch.
-usage: ab_step.py <module.attr> [batch]   e.g.  ab_step.py ops.USE_PRODUCER_STATS 8"""
+usage: ab_step.py <module.attr | lib:debug> [batch] [f32]   e.g.  ab_step.py ops.USE_PRODUCER_STATS 8"""
 import sys; sys.path.insert(0, '.')
 import importlib, torch, sd_amd
 from sd_amd import clip, diffusion, engine, ops, pipeline, synth
 torch.set_grad_enabled(False)
-mod, attr = sys.argv[1].rsplit(".", 1)
-target = importlib.import_module("sd_amd." + mod)
+# "lib:<debug>" arms: False = sdamd_set_gemm_impl(<debug> << 8) while capturing, True = the library's defaults
+if sys.argv[1].startswith("lib:"):
+    from sd_amd import _lib
+    class _LibSwitch:
+        def __setattr__(self, name, val):
+            _lib.lib().sdamd_set_gemm_impl(0 if val else int(name) << 8)
+    target, attr = _LibSwitch(), sys.argv[1][4:]
+else:
+    mod, attr = sys.argv[1].rsplit(".", 1)
+    target = importlib.import_module("sd_amd." + mod)
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+DT = torch.float32 if (len(sys.argv) > 3 and sys.argv[3] == "f32") else torch.bfloat16
 dev = torch.device("cuda")
-dm = engine.set_compute_dtype(synth.load_hashed(diffusion.Diffusion(), "diffusion.").to(dev), torch.bfloat16)
+dm = engine.set_compute_dtype(synth.load_hashed(diffusion.Diffusion(), "diffusion.").to(dev), DT)
 cm = synth.load_hashed(clip.CLIP(), "clip.").to(dev)
 pos = torch.tensor([synth.synthetic_token_ids(i) for i in range(B)], device=dev)
 neg = torch.tensor([synth.EMPTY_PROMPT_IDS] * B, device=dev)
@@ -18,6 +27,7 @@ loops = {}
 for val in (False, True):
     setattr(target, attr, val)
     loops[val] = pipeline.DenoiseLoop(dm, ctx, ts, coef, noise, lat, 7.5)
+setattr(target, attr, True)
 def step_ms(loop, n=12):
     loop.reset(lat)
     loop.step(); loop.step()

@@ -674,6 +674,7 @@ int launch_splitk_reduce(const GemmArgs& a, hipStream_t st) {
 // mode: 0 = auto, 2 = any fitting tile however few workgroups, 3 = as 2 plus a 3-way K split.
 // Returns BM*1000+BN (0: use the 4-wave kernels of gemm_conv.hip) and *splits.
 int gemm2_choose_tile(int M, int N, int K, int batch, int mode, size_t ws_bytes, int* splits, int bke, int* stages) {
+  extern int g_gemm_debug;
   if (stages) *stages = 2;
   auto blocks = [&](int bm, int bn) { return (long long)((M + bm - 1) / bm) * ((N + bn - 1) / bn) * batch; };
   const int nk = K / bke;
@@ -685,9 +686,8 @@ int gemm2_choose_tile(int M, int N, int K, int batch, int mode, size_t ws_bytes,
     if (tile && mode == 3 && nk >= 3 && max_splits() >= 3) *splits = 3;
     return tile;
   }
-  extern int g_gemm_debug;
   if (g_gemm_debug >= 32) {   // experiment: forced tile / split (debug = 32 + 8*tile + splits)
-    static const int tiles[8] = {128160, 128320, 256256, 128128, 256320, 128160, 0, 0};   // index 5: 128x160 with a 3-stage ring
+    static const int tiles[8] = {128160, 128320, 256256, 128128, 256320, 128160, 64160, 0};   // index 5: 128x160 with a 3-stage ring
     const int s = (g_gemm_debug - 32) & 7;
     if (s >= 1 && s <= max_splits() && s <= nk) *splits = s;
     const int ti = ((g_gemm_debug - 32) >> 3) & 7;
@@ -699,6 +699,16 @@ int gemm2_choose_tile(int M, int N, int K, int batch, int mode, size_t ws_bytes,
   // short-K GEMMs with many 128x320 tiles (measured at UNet batch 16, experiments/gemm_bench.py 0,8448)
   const long long b160 = N % 160 == 0 ? blocks(128, 160) : 0, b320 = N % 320 == 0 ? blocks(128, 320) : 0;
   if (bke == 64 && b160 >= 512 && (K >= 2560 || b320 < 512)) return 128160;
+  // 64x160 tile (4 waves, two workgroups per CU).  In forced-tile microbenchmarks (experiments/ab_tile64_b16.py,
+  // ab_tile64.py) it beat the 128-row plans on the bf16 16x16-level GEMMs (M 4096 N 1280: K 2560 49.1 -> 39.2 us) and the
+  // 8x8-level convs (56.7 -> 51.2 us), but the same rules measured IN SITU (experiments/ab_step.py lib:16, captured UNet
+  // step, same process) were +0.3 % at UNet batch 16 and +3.3 % at batch 2, so bf16 keeps the 128-row plans.  Kept for
+  // f32: M 8192 N 320 short-K GEMMs (64x64 level at UNet batch 2), where un-split 64x160 fills the chip once
+  // (32.3 -> 24.1 us) and the alternative is the register-staged 128x64 kernel; g_gemm_debug == 16 switches it off.
+  if (g_gemm_debug != 16 && N % 160 == 0 && bke == 32) {
+    const long long b64 = blocks(64, 160);
+    if (b160 < 256 && b64 >= 256 && b320 < 256 && nk <= 40) return 64160;
+  }
   if (b320 >= 256) return 128320;
   if (bke == 32) {
     // f32 operands (exact 16x16x4 MFMA, ~4x the issue cycles per byte staged): the 8-wave layout only
@@ -751,6 +761,7 @@ static int launch_gemm2_t(GemmArgs& a, int batch, bool conv, int mode, hipStream
         if (stages == 3) return conv ? launch2<T, 128, 160, 2, 2, 3, true>(a, batch, st) : launch2<T, 128, 160, 2, 2, 3, false>(a, batch, st);
       }
       return conv ? launch2<T, 128, 160, 2, 2, 2, true>(a, batch, st) : launch2<T, 128, 160, 2, 2, 2, false>(a, batch, st);
+    case 64160: return conv ? launch2<T, 64, 160, 2, 2, 2, true>(a, batch, st) : launch2<T, 64, 160, 2, 2, 2, false>(a, batch, st);
     case 128320: return conv ? launch2<T, 128, 320, 2, 4, 2, true>(a, batch, st) : launch2<T, 128, 320, 2, 4, 2, false>(a, batch, st);
     case 256256: return conv ? launch2<T, 256, 256, 2, 4, 2, true>(a, batch, st) : launch2<T, 256, 256, 2, 4, 2, false>(a, batch, st);
     case 256320:

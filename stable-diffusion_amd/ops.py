@@ -93,7 +93,7 @@ def _tile_tag(M, N, K, dtype, ws, batch=1, act=0, f32_residual=False, conv=False
     epilogue instantiations."""
     t = _lib.lib().sdamd_gemm_tile(M, N, K, batch, _code(dtype), ws.numel(), int(act))
     t, s = t % 1000000, t // 1000000 + 1
-    rp = f32_residual and s == 1 and gemm_supports_act(ACT_GEGLU, torch.bfloat16, 256) and (t == 128160 or (t == 128320 and not conv))
+    rp = f32_residual and s == 1 and gemm_supports_act(ACT_GEGLU, torch.bfloat16, 256) and (t in (64160, 128160) or (t == 128320 and not conv))
     return f"{t // 1000}x{t % 1000}" + (f"_splitk{s}" if s > 1 else "_rp" if rp else "_geglu" if int(act) == ACT_GEGLU and t != 0 else "")
 
 
@@ -434,7 +434,7 @@ def gemm_hilo_fused(M, N, K, dtype):
     if dtype != torch.bfloat16 or not gemm_supports_act(ACT_GEGLU, dtype, 256):    # 4-wave kernels forced
         return False
     tile = _lib.lib().sdamd_gemm_tile(M, N, K, 1, _code(dtype), GEMM_WS_BYTES, 0) % 1000000
-    return tile in (128160, 128320, 256256)      # the LDS-DMA tiles (gemm2.hip); the 4-wave ones have no such epilogue
+    return tile in (64160, 128160, 128320, 256256, 256320)      # the LDS-DMA tiles (gemm2.hip); the register-staged ones have no such epilogue
 
 
 def gemm(a, w, bias=None, residual=None, act=ACT_NONE, out_f32=False, out_hilo=False, flops_k=None, want_stats=False):

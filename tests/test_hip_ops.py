@@ -475,9 +475,10 @@ def test_small_channel_convs(dtype):
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("B,H,Cin,Cout,res", [(8, 32, 64, 320, True), (8, 32, 64, 320, False), (1, 64, 64, 640, True),
                                                (16, 64, 64, 320, True), (2, 32, 320, 320, True)])   # last: split-K plan, no statistics
-def test_conv_epilogue_column_stats_feed_groupnorm(dtype, B, H, Cin, Cout, res):
+def test_conv_epilogue_column_stats_feed_groupnorm(dtype, B, H, Cin, Cout, res, monkeypatch):
     """conv3x3(want_stats=True) leaves per-64-row-block column sums of the values it stored; groupnorm() then skips its
     own statistics pass.  Checked: the partial sums themselves, and GroupNorm(+SiLU) == the two-pass kernel's result."""
+    monkeypatch.setattr(ops, "PRODUCER_STATS_MIN_ELEMS", 0)      # (the models only ask from 8 M elements up)
     x = q(rnd(f"cst.x.{Cin}.{H}", (B, H, H, Cin)), dtype).to(dtype).to(DEV)
     w = q(rnd(f"cst.w.{Cin}.{Cout}", (Cout, 9 * Cin), 1.0 / math.sqrt(9 * Cin)), dtype).to(dtype).to(DEV)
     b = rnd(f"cst.b.{Cout}", (Cout,)).to(DEV)
@@ -510,9 +511,10 @@ def test_conv_epilogue_column_stats_feed_groupnorm(dtype, B, H, Cin, Cout, res):
         assert rel_l2(got.float().cpu(), want.float().cpu()) < tol(dtype, 2e-6, 4e-3)
 
 
-def test_gemm_epilogue_column_stats_and_virtual_concat():
+def test_gemm_epilogue_column_stats_and_virtual_concat(monkeypatch):
     """The 1x1 conv_output GEMM (hi|lo operand, f32 residual) leaves statistics too; GroupNorm over the virtual concat
     of two tensors that both carry statistics uses both sets."""
+    monkeypatch.setattr(ops, "PRODUCER_STATS_MIN_ELEMS", 0)
     B, HW, C1, C2 = 8, 1024, 320, 640
     a = rnd("gst.a", (B, HW, 2 * C1)).bfloat16().to(DEV)
     w = (rnd("gst.w", (C1, 2 * C1)) * (2 * C1) ** -0.5).bfloat16().to(DEV)
