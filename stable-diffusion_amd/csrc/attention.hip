@@ -59,7 +59,15 @@ constexpr float RESCALE_THR = 8.0f;
 #define ATTN_DBG(x) false
 #endif
 
-template <typename T, int D>
+// OPT (d = 40 only, where the reference rides in the QK product): after the first staged tile has set each query's
+// reference, the later tiles do not look for a row maximum at all -- scores come out of the MFMA relative to that
+// reference and go straight to exp2 (no 16 v_max, cross-half exchange, vote and branch per sub-tile).  That is exact
+// as long as no row outgrows its first-tile reference by ~2^100; the denominator (accumulated by the P V product in
+// the ones column) tells: if any query of the workgroup ends with l >= 2^100, inf or NaN, the whole workgroup runs its
+// loop again with the reference tracked per tile (the path above).  Softmax is invariant to the reference, so both
+// paths compute the same function; they differ in the rounding of P to bf16 only.
+// TRACK = true compiles the fast path out (experiments/attn_ab.py and the tests use it as the comparison).
+template <typename T, int D, bool TRACK = false>
 __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs p) {
   typedef AttnCfg<T, D> Cfg;
   constexpr int DK = Cfg::DK, DV = Cfg::DV, KS = Cfg::KS, VS = Cfg::VS, BKV = Cfg::BKV;
@@ -78,6 +86,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs p) {
   // of the 131 VALU instructions per 64-key tile in a VALU-issue-bound loop).  The reference still only moves when a
   // row outgrows it by 2^RESCALE_THR; tiles where it moves subtract the difference explicitly (rare path).
   constexpr bool AUG = BF && DK > D && ONES;
+  constexpr bool OPT = AUG && !TRACK;
   constexpr int L_BLK = D / 32, L_REG = ((D % 32) & 3) + 4 * ((D % 32) >> 3), L_HALF = ((D % 32) >> 2) & 1;
   constexpr int NQ = BF ? DK / 16 : D / 8;                   // Q fragments (4 VGPR each)
   constexpr int KCH = BKV * KC, VCH = BKV * VC;              // chunks per staged tile
@@ -172,19 +181,24 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs p) {
     }
   }
 
-  f32x16_t o[NB];
-#pragma unroll
-  for (int i = 0; i < NB; ++i)
-#pragma unroll
-    for (int e = 0; e < 16; ++e) o[i][e] = 0.f;
-  float m_run = AUG ? 0.f : -1.0e30f, l_run = 0.f;  // running max (scaled, log2 domain) and denominator
-  float m_qk = 0.f;                                    // AUG: the reference currently baked into Q[:, D]
-
   // causal: this block needs keys 0 .. q0_block+127 only
   int kv_end = p.Skv;
   if (p.causal) kv_end = min(p.Skv, (int)blockIdx.x * 128 + 128);
   const int ntiles = (kv_end + BKV - 1) / BKV;
   const float sc = p.scale_log2e;
+  int* redo = reinterpret_cast<int*>(smem + 2 * STAGE);   // OPT: "some row overflowed" flag (the launch adds 16 bytes)
+  if (OPT && t == 0) *redo = 0;
+
+  f32x16_t o[NB];
+  float m_run, l_run, m_qk;
+  bool safe = !OPT;                                        // track the reference in every tile (wave-uniform)
+  for (;;) {
+#pragma unroll
+  for (int i = 0; i < NB; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) o[i][e] = 0.f;
+  m_run = AUG ? 0.f : -1.0e30f, l_run = 0.f;  // running max (scaled, log2 domain) and denominator
+  m_qk = 0.f;                                   // AUG: the reference currently baked into Q[:, D]
 
   issue(0);
   commit(0);
@@ -227,6 +241,13 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs p) {
         for (int e = 0; e < 16; ++e) {
           const int key = kv0 + sub * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
           if (key >= p.Skv || (p.causal && key > qrow)) s[sub][e] = -1.0e30f;
+        }
+      }
+      if constexpr (OPT) {
+        if (!safe && kt > 0) {   // reference fixed by tile 0 and baked into Q: the MFMA result is the exponent
+#pragma unroll
+          for (int e = 0; e < 16; ++e) s[sub][e] = __builtin_amdgcn_exp2f(s[sub][e]);
+          return;
         }
       }
       float mx = -1.0e30f;
@@ -339,6 +360,18 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs p) {
     if (kt + 1 < ntiles && !ATTN_DBG(4) && !ATTN_DBG(5)) commit((kt + 1) & 1);
     if (!ATTN_DBG(5)) __syncthreads();
   }
+  if constexpr (!OPT) {
+    break;
+  } else {
+    if (safe) break;
+    const float l = __shfl(o[L_BLK][L_REG], r + 32 * L_HALF, 64);
+    if (__any(!(l < 0x1p100f)) && lane == 0) *redo = 1;
+    __syncthreads();                 // also: every wave is done with the staged tiles before tile 0 is staged again
+    if (*redo == 0) break;
+    safe = true;
+    if (h == 1) qf[NQ - 1][0] &= 0xffff0000u;   // Q[:, D] = 0 again
+  }
+  }
 
   // epilogue: O[q][d] = O^T[d][q] / l ; lane holds d = 32i + 8*(e>>2) + 4h + (e&3)
   if (qrow < p.Sq) {
@@ -365,14 +398,14 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs p) {
   }
 }
 
-template <typename T, int D>
+template <typename T, int D, bool TRACK = false>
 static int launch_attn(const AttnArgs& a, int B, hipStream_t st) {
   dim3 grid((a.Sq + 127) / 128, B * a.H);
-  constexpr int lds = 2 * AttnCfg<T, D>::STAGE;
+  constexpr int lds = 2 * AttnCfg<T, D>::STAGE + 16;   // + the fast path's redo flag
   static std::atomic<unsigned long long> lds_ok{0};
-  if (lds > 48 * 1024 && sd_lds_opt_in(lds_ok, (const void*)attn_kernel<T, D>, lds) != hipSuccess)
+  if (lds > 48 * 1024 && sd_lds_opt_in(lds_ok, (const void*)attn_kernel<T, D, TRACK>, lds) != hipSuccess)
     return sdamd_set_error(2, "attention: cannot reserve %d bytes of LDS", lds);
-  attn_kernel<T, D><<<grid, 256, lds, st>>>(a);
+  attn_kernel<T, D, TRACK><<<grid, 256, lds, st>>>(a);
   SD_LAUNCH_CHECK("attention");
   return 0;
 }
@@ -641,6 +674,7 @@ extern "C" int sdamd_attention(const void* q, const void* k, const void* v, void
   { extern int g_gemm_debug; a.debug = g_gemm_debug; }
   hipStream_t st = (hipStream_t)stream;
   if (d == 512) return dtype == SDAMD_BF16 ? launch_attn512<bf16_t>(a, B, st) : launch_attn512<float>(a, B, st);
+  if (d == 40 && dtype == SDAMD_BF16 && a.debug == 17) return launch_attn<bf16_t, 40, true>(a, B, st);
 #define ATT(TT) switch (d) { case 40: return launch_attn<TT, 40>(a, B, st); case 64: return launch_attn<TT, 64>(a, B, st); \
                              case 80: return launch_attn<TT, 80>(a, B, st); default: return launch_attn<TT, 160>(a, B, st); }
   if (dtype == SDAMD_BF16) ATT(bf16_t) else ATT(float)

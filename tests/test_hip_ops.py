@@ -567,6 +567,41 @@ def test_flash_attention_fused_qkv_views_and_spiky_scores(dtype):
     assert rel_l2(got.float().cpu(), want) < tol(dtype, 3e-6, 1e-2)
 
 
+def test_flash_attention_d40_fixed_reference_fast_path_and_its_fallback():
+    """bf16 d = 40 keeps each query's first-tile softmax reference for the whole sweep and checks the denominator at
+    the end (attention.hip, OPT); a workgroup whose rows outgrow that reference by ~2^100 runs again with the
+    reference tracked per tile.  Three regimes: ordinary scores (both forms take the same arithmetic: bit-equal),
+    late keys 2^30..2^90 above the first tile (fast path only, P large but finite), late keys > 2^100 above (fallback).
+    The comparison form (reference tracked in every tile) is selected with debug word 17."""
+    from sd_amd import _lib
+    L = _lib.lib()
+    B, S, H, d = 2, 1024, 8, 40
+    C = H * d
+    base = rnd("att.fastpath", (B, S, 3 * C))
+    for amp, bit_equal in ((1.0, True), (3.0, False), (30.0, False)):
+        qkv = base.clone()
+        qkv[:, S // 2:, C:2 * C] *= amp
+        qkv[..., :C] *= amp ** 0.5
+        qkv = q(qkv, torch.bfloat16)
+        dv = qkv.to(torch.bfloat16).to(DEV)
+        qv, kv, vv = dv[..., :C], dv[..., C:2 * C], dv[..., 2 * C:]
+        got = ops.attention(qv, kv, vv, H)
+        try:
+            L.sdamd_set_gemm_impl(17 << 8)
+            tracked = ops.attention(qv, kv, vv, H)
+        finally:
+            L.sdamd_set_gemm_impl(0)
+        assert torch.isfinite(got.float()).all()
+        if bit_equal:
+            assert torch.equal(got, tracked)
+            want = O.attention_core(qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:], H)
+            assert rel_l2(got.float().cpu(), want) < 1e-2
+        else:
+            # same function, P rounded to bf16 at a different reference: both within the same distance of each other
+            # as either is of the oracle at these score magnitudes (Q is rounded to bf16 after scaling, see AUG)
+            assert rel_l2(got.float().cpu(), tracked.float().cpu()) < 3e-2
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_flash_attention_vae_head_full_size_and_spiky(dtype):
     """decoder.py:39-70 at its real size (one head of 512, S = 4096 = the 64x64 map of a 512^2 image): strided views of
