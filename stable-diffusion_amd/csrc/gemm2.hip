@@ -75,7 +75,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm2_kernel(const GemmArgs p) 
   constexpr int MIN_PIECES = A_PIECES / NW + B_PIECES / NW;   // fewest pieces any wave issues per tile
   constexpr int NPIECE = A_INS + B_INS;
   constexpr int STAGE = (BM + BN) * 128;
-  static_assert(BM % 8 == 0 && BN % 8 == 0 && WTM % 16 == 0 && WTN % 16 == 0 && (STAGES == 2 || STAGES == 3), "tile shape");
+  static_assert(BM % 8 == 0 && BN % 8 == 0 && WTM % 16 == 0 && WTN % 16 == 0 && STAGES >= 2 && STAGES <= 4, "tile shape");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   // XCD-aware (bijective) tile order, n fastest: an XCD's run of tiles shares A rows and the W panel
@@ -285,7 +285,9 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm2_kernel(const GemmArgs p) 
   }
   int kt = 0;
   stage_tile(smem, kt_begin * BKE);
-  if (STAGES == 3 && nk > 1) stage_tile(smem + STAGE, (kt_begin + 1) * BKE);
+#pragma unroll
+  for (int s = 1; s < STAGES - 1; ++s)
+    if (nk > s) stage_tile(smem + s * STAGE, (kt_begin + s) * BKE);
   // f32 residual prefetch: the epilogue's residual chunks (same (m, n) per lane as its row-segment stores) are
   // requested here, behind the first K-tile's DMA, so the fetch overlaps the K loop instead of standing between
   // the last MFMA and the first store -- the short-K GEMMs on the f32 trunk are bound by exactly those bytes.
@@ -320,11 +322,18 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm2_kernel(const GemmArgs p) 
       GEMM2_STEP(0, 1)
       GEMM2_STEP(1, 0)
     }
-  } else {
+  } else if (STAGES == 3) {
     for (;;) {
       GEMM2_STEP(0, 2)
       GEMM2_STEP(1, 0)
       GEMM2_STEP(2, 1)
+    }
+  } else {
+    for (;;) {
+      GEMM2_STEP(0, 3)
+      GEMM2_STEP(1, 0)
+      GEMM2_STEP(2, 1)
+      GEMM2_STEP(3, 2)
     }
   }
 #undef GEMM2_STEP
@@ -687,11 +696,12 @@ int gemm2_choose_tile(int M, int N, int K, int batch, int mode, size_t ws_bytes,
     return tile;
   }
   if (g_gemm_debug >= 32) {   // experiment: forced tile / split (debug = 32 + 8*tile + splits)
-    static const int tiles[8] = {128160, 128320, 256256, 128128, 256320, 128160, 64160, 0};   // index 5: 128x160 with a 3-stage ring
+    static const int tiles[8] = {128160, 128320, 256256, 128128, 256320, 128160, 64160, 64160};   // index 5: 128x160 with a 3-stage ring, 7: 64x160 with a 4-stage ring
     const int s = (g_gemm_debug - 32) & 7;
     if (s >= 1 && s <= max_splits() && s <= nk) *splits = s;
     const int ti = ((g_gemm_debug - 32) >> 3) & 7;
     if (stages && ti == 5) *stages = 3;
+    if (stages && ti == 7) *stages = 4;
     return tiles[ti];
   }
   // bf16: the 4-wave 128x160 tile (two co-resident workgroups per CU overlap each other's prologue and
@@ -757,11 +767,11 @@ static int launch_gemm2_t(GemmArgs& a, int batch, bool conv, int mode, hipStream
   switch (tile) {
     case 128128: return conv ? -1 : launch2<T, 128, 128, 2, 2, 2, false>(a, batch, st);
     case 128160:
-      if constexpr (sizeof(T) == 2) {
-        if (stages == 3) return conv ? launch2<T, 128, 160, 2, 2, 3, true>(a, batch, st) : launch2<T, 128, 160, 2, 2, 3, false>(a, batch, st);
-      }
+      if (stages == 3) return conv ? launch2<T, 128, 160, 2, 2, 3, true>(a, batch, st) : launch2<T, 128, 160, 2, 2, 3, false>(a, batch, st);
       return conv ? launch2<T, 128, 160, 2, 2, 2, true>(a, batch, st) : launch2<T, 128, 160, 2, 2, 2, false>(a, batch, st);
-    case 64160: return conv ? launch2<T, 64, 160, 2, 2, 2, true>(a, batch, st) : launch2<T, 64, 160, 2, 2, 2, false>(a, batch, st);
+    case 64160:
+      if (stages == 4) return conv ? launch2<T, 64, 160, 2, 2, 4, true>(a, batch, st) : launch2<T, 64, 160, 2, 2, 4, false>(a, batch, st);
+      return conv ? launch2<T, 64, 160, 2, 2, 2, true>(a, batch, st) : launch2<T, 64, 160, 2, 2, 2, false>(a, batch, st);
     case 128320: return conv ? launch2<T, 128, 320, 2, 4, 2, true>(a, batch, st) : launch2<T, 128, 320, 2, 4, 2, false>(a, batch, st);
     case 256256: return conv ? launch2<T, 256, 256, 2, 4, 2, true>(a, batch, st) : launch2<T, 256, 256, 2, 4, 2, false>(a, batch, st);
     case 256320:
