@@ -9,7 +9,8 @@ if sys.argv[1].startswith("lib:"):
     from sd_amd import _lib
     class _LibSwitch:
         def __setattr__(self, name, val):
-            _lib.lib().sdamd_set_gemm_impl(0 if val else int(name) << 8)
+            if name == "f32exact": _lib.lib().sdamd_set_f32_mode(1 if val else 0)   # False arm = exact f32 MFMA
+            else: _lib.lib().sdamd_set_gemm_impl(0 if val else int(name) << 8)
     target, attr = _LibSwitch(), sys.argv[1][4:]
 else:
     mod, attr = sys.argv[1].rsplit(".", 1)

@@ -169,6 +169,15 @@ int sdamd_gemm_supports_act(int act, int dtype, int N);
  * one of their tiles divides N, 3 = as 2 with a 3-way K split (small-size parity tests);
  * returns the previous value */
 int sdamd_set_gemm_impl(int impl);
+/* How f32 GEMM / conv3x3 operands (dtype SDAMD_F32) reach the matrix cores; returns the previous mode, any other
+ * argument only queries.  No reference counterpart: torch's fp32 nn.Linear / nn.Conv2d (diffusion.py, decoder.py) is
+ * the function both modes compute.
+ *   1 (default) "bf16x3": every f32 operand value is split exactly into three bf16 terms in registers and a product is
+ *      accumulated in f32 from the six partial products >= 2^-16 of it on v_mfma_f32_16x16x32_bf16; the dropped terms
+ *      are below one f32 rounding of the product.  Measured against float64 the result is as close as mode 0's
+ *      (tests/test_hip_ops.py::test_f32_modes_against_float64), at 1.3-1.5x its speed.  inf inputs give NaN.
+ *   0 "exact": v_mfma_f32_16x16x4_f32, bitwise an fmaf chain over k. */
+int sdamd_set_f32_mode(int mode);
 /* ---- implicit-GEMM conv3x3 over NHWC: nn.Conv2d(k=3) of diffusion.py:9,13,146,204-221,
  * decoder.py:10-13,92-111, encoder.py:13-45.  w [Cout][ky][kx][Cin]; pad_mode 0 = pad 1,
  * 1 = bottom/right pad only (encoder.py:65-66); upsample=1 fuses F.interpolate(nearest,2x)

@@ -47,6 +47,7 @@ SIGNATURES = {
     "sdamd_gemm": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _ll, _ll, _ll, _ll, _i, _i, _i, _vp, _sz, _vp, _vp, _vp]),
     "sdamd_gemm_tile": (_i, [_i, _i, _i, _i, _i, _sz, _i]),
     "sdamd_set_gemm_impl": (_i, [_i]),
+    "sdamd_set_f32_mode": (_i, [_i]),
     "sdamd_gemm_supports_act": (_i, [_i, _i, _i]),
     "sdamd_conv3x3": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp, _vp, _vp]),
     "sdamd_conv3x3_cin_small": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
@@ -74,6 +75,8 @@ def lib():
             fn = getattr(handle, name)   # AttributeError if the .so does not export a declared symbol
             fn.restype = res
             fn.argtypes = args
+        if os.environ.get("SDAMD_F32_MODE", "") == "exact":   # exact f32 MFMA instead of the bf16x3 products (include/sdamd.h)
+            handle.sdamd_set_f32_mode(0)
         _lib = handle
     return _lib
 

@@ -63,6 +63,7 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
 template <typename T, int BM, int BN, int WGM, int WGN, int STAGES, bool CONV, int EPI>
 __global__ __launch_bounds__(WGM* WGN * 64) void gemm2_kernel(const GemmArgs p) {
   constexpr bool F32 = sizeof(T) == 4;     // exact-f32 MFMA (v_mfma_f32_16x16x4_f32) on f32 operands
+  constexpr bool EMU = std::is_same<T, f32e_t>::value;   // f32 operands split into 3 bf16 terms, 6 bf16 MFMAs (see split3_bf16)
   constexpr int EPC = 16 / sizeof(T);      // elements per 16-byte chunk
   constexpr int BKE = 8 * EPC;             // K elements per 128-byte tile row (64 bf16 / 32 f32)
   constexpr int NW = WGM * WGN;
@@ -216,7 +217,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm2_kernel(const GemmArgs p) 
     // tile, i.e. an exposed LDS latency every 64 MFMA cycles.
     // Measured (same box, experiments/gemm_bench.py): +3-9 % on the 8-wave 128x320 tile, -35 % on the 4-wave
     // 128x160 tile (two workgroups per CU: its waves interleave best at the compiler's fine grain), so 8 waves only.
-    constexpr bool PREFETCH = !INTERLEAVE_DMA && NW == 8 && (TM + TN) <= 9;
+    constexpr bool PREFETCH = !INTERLEAVE_DMA && !EMU && NW == 8 && (TM + TN) <= 9;
     frag_t xf[2][TM], wf[2][TN];
     auto load_frags = [&](int g) {
 #pragma unroll
@@ -239,6 +240,27 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm2_kernel(const GemmArgs p) 
       }
       __builtin_amdgcn_sched_group_barrier(0x008, NMF - PER * NRD, 0);
     }
+    if constexpr (EMU) {
+      load_frags(0);
+      load_frags(1);
+      bf16x8_t xh[TM], xm[TM], xl[TM];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) split3_bf16(xf[0][i], xf[1][i], xh[i], xm[i], xl[i]);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        bf16x8_t wh, wm, wl;
+        split3_bf16(wf[0][j], wf[1][j], wh, wm, wl);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {   // small terms first
+          acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, xh[i], acc[j][i], 0, 0, 0);
+          acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xl[i], acc[j][i], 0, 0, 0);
+          acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, xm[i], acc[j][i], 0, 0, 0);
+          acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, xh[i], acc[j][i], 0, 0, 0);
+          acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xm[i], acc[j][i], 0, 0, 0);
+          acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh[i], acc[j][i], 0, 0, 0);
+        }
+      }
+    } else
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
       if constexpr (!PREFETCH) load_frags(g);
@@ -782,5 +804,7 @@ static int launch_gemm2_t(GemmArgs& a, int batch, bool conv, int mode, hipStream
 }
 
 int launch_gemm2(GemmArgs& a, int dtype, int batch, bool conv, int mode, hipStream_t st) {
+  extern int g_f32_emu;
+  if (dtype != SDAMD_BF16 && g_f32_emu) return launch_gemm2_t<f32e_t>(a, batch, conv, mode, st);
   return dtype == SDAMD_BF16 ? launch_gemm2_t<bf16_t>(a, batch, conv, mode, st) : launch_gemm2_t<float>(a, batch, conv, mode, st);
 }

@@ -36,6 +36,36 @@ struct GemmArgs {
 };
 
 
+#ifdef __HIPCC__
+// f32 operands on the bf16 matrix pipe ("bf16x3"): every f32 value is split exactly into three bf16 terms
+// a = hi + mid + lo (8 + 8 + 8 significant bits; each residual is exact in f32), and a product a*w is accumulated in
+// f32 from the six terms of weight >= 2^-16: hi*hi, hi*mid, mid*hi, hi*lo, lo*hi, mid*mid.  The dropped terms
+// (mid*lo, lo*mid, lo*lo) are <= 3 * 2^-24 |a w|, the size of one f32 rounding of the product, so the result is an
+// f32 GEMM to within f32 rounding -- at 6 x v_mfma_f32_16x16x32_bf16 (96 cycles per 16x16x32 block) instead of
+// 8 x v_mfma_f32_16x16x4_f32 (256 cycles).  Operands are staged as f32 exactly as in the exact-f32 kernel; the split
+// is done on the fragments in registers (11 VALU per element pair).  Non-finite inputs give NaN (inf - inf in the
+// residual) where the exact kernel would give inf.
+struct f32e_t { float v; };
+template <> struct Cvt<f32e_t> {   // (only reached for f32 outputs: the bf16-output branches are dead for 4-byte operands)
+  static __device__ __forceinline__ float ld(const f32e_t* p) { return p->v; }
+  static __device__ __forceinline__ void st(f32e_t* p, float v) { p->v = v; }
+};
+__device__ __forceinline__ void split3_bf16(const f32x4_t a, const f32x4_t b, bf16x8_t& hi, bf16x8_t& mid, bf16x8_t& lo) {
+  const float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+  u32x4_t h, m, l;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float a0 = v[2 * q], a1 = v[2 * q + 1];
+    const unsigned hp = pack_bf2(a0, a1);
+    const float r0 = a0 - __builtin_bit_cast(float, hp << 16), r1 = a1 - __builtin_bit_cast(float, hp & 0xffff0000u);
+    const unsigned mp = pack_bf2(r0, r1);
+    const float s0 = r0 - __builtin_bit_cast(float, mp << 16), s1 = r1 - __builtin_bit_cast(float, mp & 0xffff0000u);
+    h[q] = hp; m[q] = mp; l[q] = pack_bf2(s0, s1);
+  }
+  hi = __builtin_bit_cast(bf16x8_t, h); mid = __builtin_bit_cast(bf16x8_t, m); lo = __builtin_bit_cast(bf16x8_t, l);
+}
+#endif
+
 // gemm2.hip: 8-wave, LDS-DMA-staged kernels (bf16 and exact-f32 MFMA).  Returns -1 when no tile configuration of that
 // family fits the problem (the caller then uses the 4-wave register-staged kernels), 0 on launch.
 int launch_gemm2(GemmArgs& a, int dtype, int batch, bool conv, int mode, hipStream_t st);   // mode: g_gemm_impl

@@ -24,6 +24,7 @@
 template <typename T> struct Frag;
 template <> struct Frag<bf16_t> { typedef bf16x8_t type; };
 template <> struct Frag<float> { typedef f32x4_t type; };
+template <> struct Frag<f32e_t> { typedef f32x4_t type; };   // f32 operands, bf16x3 products (gemm_common.h)
 
 template <typename T>
 __device__ __forceinline__ void mma16(f32x4_t& acc, const typename Frag<T>::type& w, const typename Frag<T>::type& x);
@@ -143,6 +144,29 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
     if (kt + 1 < nk) issue_loads((kt_begin + kt + 1) * BKE);
     const char* sa = smem + cur * STAGE;
     const char* sw = sa + BM * 128;
+    if constexpr (std::is_same<T, f32e_t>::value) {
+      bf16x8_t xh[TM], xm[TM], xl[TM];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int row = wm * (BM / 2) + i * 16 + r16;
+        split3_bf16(*reinterpret_cast<const f32x4_t*>(sa + swz_off(row, q4)), *reinterpret_cast<const f32x4_t*>(sa + swz_off(row, 4 + q4)), xh[i], xm[i], xl[i]);
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int row = wn * (BN / 2) + j * 16 + r16;
+        bf16x8_t wh, wmid, wl;
+        split3_bf16(*reinterpret_cast<const f32x4_t*>(sw + swz_off(row, q4)), *reinterpret_cast<const f32x4_t*>(sw + swz_off(row, 4 + q4)), wh, wmid, wl);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, xh[i], acc[j][i], 0, 0, 0);
+          acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xl[i], acc[j][i], 0, 0, 0);
+          acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wmid, xm[i], acc[j][i], 0, 0, 0);
+          acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wmid, xh[i], acc[j][i], 0, 0, 0);
+          acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xm[i], acc[j][i], 0, 0, 0);
+          acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh[i], acc[j][i], 0, 0, 0);
+        }
+      }
+    } else
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
       frag_t xf[TM], wf[TN];
@@ -404,6 +428,10 @@ static int choose_tile(int M, int N, int batch) {
 // few workgroups that makes, 3 = as 2 with a 3-way K split (parity tests at small sizes).
 static int g_gemm_impl = 0;
 int g_gemm_debug = 0;
+// f32 operands: 1 = products on the bf16 matrix pipe from three-term operand splits (six MFMAs, gemm_common.h
+// split3_bf16: f32-rounding-level accuracy at ~2.7x the matrix rate of v_mfma_f32_16x16x4_f32), 0 = exact f32 MFMA.
+int g_f32_emu = 1;
+extern "C" int sdamd_set_f32_mode(int mode) { int old = g_f32_emu; if (mode == 0 || mode == 1) g_f32_emu = mode; return old; }
 extern "C" int sdamd_set_gemm_impl(int impl) { int old = g_gemm_impl; g_gemm_impl = impl & 255; g_gemm_debug = impl >> 8; return old; }
 
 // 1 when sdamd_gemm can run `act` fused for this dtype / N with the current kernel family selection
@@ -470,6 +498,7 @@ extern "C" int sdamd_gemm(const void* A, const void* W, void* C, const float* bi
   SD_CHECK(act != ACT_GEGLU, "gemm: the fused GeGLU epilogue needs bf16, N %% 256 == 0, no residual, bf16 output and the 8-wave kernels");
   SD_CHECK(out_f32 != 2, "gemm: the hi|lo output needs bf16 operands and a shape the LDS-DMA kernels take (sdamd_gemm_tile != 0)");
   if (dtype == SDAMD_BF16) return pick_tile<bf16_t, false>(a, batch, st);
+  if (g_f32_emu) return pick_tile<f32e_t, false>(a, batch, st);
   return pick_tile<float, false>(a, batch, st);
 }
 
@@ -545,6 +574,7 @@ extern "C" int sdamd_conv3x3(const void* x, const void* w, void* y, const float*
     if (r >= 0) { if (colstats_written && r == 0) *colstats_written = a.colstats_done; return r; }
   }
   if (dtype == SDAMD_BF16) return pick_tile<bf16_t, true>(a, 1, st);
+  if (g_f32_emu) return pick_tile<f32e_t, true>(a, 1, st);
   return pick_tile<float, true>(a, 1, st);
 }
 

@@ -499,6 +499,21 @@ def _stats_attach(out, stats, wrote):
         out._sd_colstats = stats
 
 
+F32_MODES = {"exact": 0, "bf16x3": 1}
+
+
+def set_f32_mode(mode):
+    """How fp32 GEMM / conv3x3 operands reach the matrix cores (include/sdamd.h, sdamd_set_f32_mode): "bf16x3" (default:
+    three-term bf16 split, six MFMA products, f32-rounding-level accuracy) or "exact" (f32 MFMA, an fmaf chain over k).
+    Returns the previous mode's name.  Process-wide; a captured DenoiseLoop keeps the mode it was captured under."""
+    old = _lib.lib().sdamd_set_f32_mode(F32_MODES[mode])
+    return "bf16x3" if old else "exact"
+
+
+def get_f32_mode():
+    return "bf16x3" if _lib.lib().sdamd_set_f32_mode(-1) else "exact"
+
+
 def gemm_supports_act(act, dtype, N):
     return bool(_lib.lib().sdamd_gemm_supports_act(int(act), _code(dtype), int(N)))
 

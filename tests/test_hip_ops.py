@@ -620,6 +620,44 @@ def test_flash_attention_vae_head_full_size_and_spiky(dtype):
     assert rel_l2(got.float().cpu(), unfused.float().cpu()) < tol(dtype, 5e-6, 1.5e-2)
 
 
+@pytest.mark.parametrize("impl", [0, 1, 2, 3])
+def test_f32_modes_against_float64(impl):
+    """include/sdamd.h sdamd_set_f32_mode: the default fp32 path forms each product from three-term bf16 splits of both
+    operands (six MFMA products); "exact" is the f32 MFMA.  Both are compared with a float64 reference: the default has to
+    be as close as the exact kernel (measured: slightly closer, fewer roundings in the accumulation), on every kernel
+    family (impl 0 auto, 1 register-staged, 2 LDS-DMA tiles, 3 LDS-DMA with split-K), GEMM and conv, with values spanning
+    20 binades and a residual."""
+    from sd_amd import _lib
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(5)
+    def wide(*shape):   # magnitudes from 2^-10 to 2^10
+        return torch.randn(*shape, generator=g) * torch.exp2(torch.randint(-10, 11, shape, generator=g).float())
+    M, N, K = 2048, 640, 640
+    a, w, r = wide(M, K), wide(N, K) * K ** -0.5, torch.randn(M, N, generator=g)
+    ref_g = a.double() @ w.double().t() + r.double()
+    x, cw, cb = wide(2, 16, 16, 320), wide(320, 9 * 320) * (9 * 320) ** -0.5, torch.randn(320, generator=g)
+    ref_c = torch.nn.functional.conv2d(x.double().permute(0, 3, 1, 2), cw.double().view(320, 3, 3, 320).permute(0, 3, 1, 2),
+                                       cb.double(), padding=1).permute(0, 2, 3, 1)
+    err = {}
+    old_impl = L.sdamd_set_gemm_impl(impl)
+    old_mode = ops.get_f32_mode()
+    try:
+        for mode in ("exact", "bf16x3"):
+            ops.set_f32_mode(mode)
+            og = ops.gemm(a.to(DEV), w.to(DEV), None, r.to(DEV)).double().cpu()
+            oc = ops.conv3x3(x.to(DEV), cw.to(DEV), cb.to(DEV), None, 1, 0, False).double().cpu()
+            err[mode] = (float((og - ref_g).norm() / ref_g.norm()), float((oc - ref_c).norm() / ref_c.norm()),
+                         float(((og - ref_g).abs() / (a.abs().double() @ w.abs().double().t() + r.abs().double())).max()))
+    finally:
+        ops.set_f32_mode(old_mode)
+        L.sdamd_set_gemm_impl(old_impl)
+    assert ops.get_f32_mode() == old_mode
+    for i in range(2):
+        assert err["exact"][i] < 2e-6 and err["bf16x3"][i] <= 1.25 * err["exact"][i] + 1e-8, err
+    # worst element relative to sum |a||w| (the accumulation's own roundings dominate both): no worse than exact either
+    assert err["exact"][2] < 5e-6 and err["bf16x3"][2] <= 1.25 * err["exact"][2], err
+
+
 def test_argument_errors_are_reported():
     from sd_amd import _lib
     a = torch.zeros((4, 100), device=DEV)
