@@ -411,6 +411,244 @@ static int launch_attn(const AttnArgs& a, int B, hipStream_t st) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// f32 attention on the bf16 matrix pipe ("bf16x3", the attention side of sdamd_set_f32_mode, include/sdamd.h).
+// Same algorithm and workgroup shape as attn_kernel (128 queries per workgroup, 32 per wave, S^T = K Q^T, online softmax
+// with a lazy reference, ones column in V for the denominator), f32 in / f32 out, but every f32 operand is split exactly
+// into three bf16 terms and each product is accumulated in f32 from its six partial products >= 2^-16 (hi*hi, hi*mid,
+// mid*hi, hi*lo, lo*hi, mid*mid; the dropped ones are below one f32 rounding of the product):
+//   Q   scaled by log2(e)/sqrt(d) in f32 and split once per query, in registers;
+//   K,V split ONCE PER WORKGROUP when a prefetched tile is committed to LDS, as three bf16 planes each (so the four
+//       waves do not repeat the split, and V^T fragments still come from ds_read_b64_tr_b16);
+//   P   = exp2(s - m), split in registers per 32x32 tile (the only per-wave split work: 88 VALU per tile).
+// Per 32-key x 32-query tile at d = 40: 42 v_mfma_f32_32x32x16_bf16 (1344 cycles) instead of 52 v_mfma_f32_32x32x2_f32
+// (3328 cycles).  32-key tiles, two LDS stages.
+// ---------------------------------------------------------------------------------------------
+template <int D> struct AttnX3Cfg {
+  static constexpr int DK = (D + 15) / 16 * 16;
+  static constexpr int DV = (D + 1 + 31) / 32 * 32;                   // always one spare column: V[:, D] = 1
+  static constexpr int KS = DK * 2 + 16;                              // bf16 plane row strides (bytes), as AttnCfg<bf16_t>
+  static constexpr int VS = (DV * 2) % 256 == 64 || (DV * 2) % 256 == 192 ? DV * 2 : DV * 2 + 64;
+  static constexpr int BKV = 32;
+  static constexpr int KP = BKV * KS, VP = BKV * VS;                  // one plane of a staged tile
+  static constexpr int STAGE = 3 * (KP + VP);                         // [K hi | K mid | K lo | V hi | V mid | V lo]
+};
+
+template <int D>
+__global__ __launch_bounds__(256) void attn_f32x3_kernel(const AttnArgs p) {
+  typedef AttnX3Cfg<D> Cfg;
+  constexpr int DK = Cfg::DK, DV = Cfg::DV, KS = Cfg::KS, VS = Cfg::VS, BKV = Cfg::BKV, KP = Cfg::KP, VP = Cfg::VP;
+  constexpr int STAGE = Cfg::STAGE;
+  constexpr int NQ = DK / 16, NB = DV / 32;
+  constexpr int DC = D / 4;                                  // 16-byte f32 chunks per global row
+  constexpr int L_BLK = D / 32, L_REG = ((D % 32) & 3) + 4 * ((D % 32) >> 3), L_HALF = ((D % 32) >> 2) & 1;
+  static_assert(D % 8 == 0 && D < DV, "head dim");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int b = blockIdx.y / p.H, head = blockIdx.y % p.H;
+  const int q0 = blockIdx.x * 128 + wave * 32;
+  const int qrow = q0 + r;
+  const float* __restrict__ Qp = (const float*)p.Q + (size_t)b * p.q_bs + (size_t)head * D;
+  const float* __restrict__ Kp = (const float*)p.K + (size_t)b * p.k_bs + (size_t)head * D;
+  const float* __restrict__ Vp = (const float*)p.V + (size_t)b * p.v_bs + (size_t)head * D;
+
+  // Q fragments (B operand of S^T = K Q^T): lane (r, h) holds Q[qrow][16s + 8h .. +7], pre-scaled, three planes
+  bf16x8_t qh[NQ], qm[NQ], ql[NQ];
+  {
+    const float* qr = Qp + (size_t)min(qrow, p.Sq - 1) * p.q_rs;
+    const float sc = p.scale_log2e;
+#pragma unroll
+    for (int s = 0; s < NQ; ++s) {
+      const int d0 = 16 * s + 8 * h;
+      f32x4_t a = {0.f, 0.f, 0.f, 0.f}, c = {0.f, 0.f, 0.f, 0.f};
+      if (d0 < D) { a = *reinterpret_cast<const f32x4_t*>(qr + d0); c = *reinterpret_cast<const f32x4_t*>(qr + d0 + 4); }
+      split3_bf16(a * sc, c * sc, qh[s], qm[s], ql[s]);
+    }
+  }
+
+  // K/V tile: f32 chunks prefetched into registers, split into planes when committed
+  constexpr int NCH = BKV * DC;
+  constexpr int PT = (NCH + 255) / 256;
+  f32x4_t rk[PT], rv[PT];
+  auto issue = [&](int kv0) {
+#pragma unroll
+    for (int i = 0; i < PT; ++i) {
+      const int c = t + 256 * i;
+      if (NCH % 256 == 0 || c < NCH) {
+        const int row = c / DC, ch = c - row * DC;
+        const size_t grow = (size_t)min(kv0 + row, p.Skv - 1);
+        rk[i] = *reinterpret_cast<const f32x4_t*>(Kp + grow * p.k_rs + ch * 4);
+        rv[i] = *reinterpret_cast<const f32x4_t*>(Vp + grow * p.v_rs + ch * 4);
+      }
+    }
+  };
+  auto commit = [&](int stage) {
+    char* ks = smem + stage * STAGE;
+    char* vs = ks + 3 * KP;
+#pragma unroll
+    for (int i = 0; i < PT; ++i) {
+      const int c = t + 256 * i;
+      if (NCH % 256 == 0 || c < NCH) {
+        const int row = c / DC, ch = c - row * DC;
+        const Split3 k0 = split3_pair(rk[i][0], rk[i][1]), k1 = split3_pair(rk[i][2], rk[i][3]);
+        const Split3 v0 = split3_pair(rv[i][0], rv[i][1]), v1 = split3_pair(rv[i][2], rv[i][3]);
+        const u32x2_t kh = {k0.h, k1.h}, km = {k0.m, k1.m}, kl = {k0.l, k1.l}, vh = {v0.h, v1.h}, vm = {v0.m, v1.m}, vl = {v0.l, v1.l};
+        char* kd = ks + row * KS + ch * 8;
+        char* vd = vs + row * VS + ch * 8;
+        *reinterpret_cast<u32x2_t*>(kd) = kh; *reinterpret_cast<u32x2_t*>(kd + KP) = km; *reinterpret_cast<u32x2_t*>(kd + 2 * KP) = kl;
+        *reinterpret_cast<u32x2_t*>(vd) = vh; *reinterpret_cast<u32x2_t*>(vd + VP) = vm; *reinterpret_cast<u32x2_t*>(vd + 2 * VP) = vl;
+      }
+    }
+  };
+  {  // constant pad chunks of both stages and all planes: zeros, and V_hi[:, D] = 1
+    constexpr int KPADC = (DK - D) / 8, VPADC = (DV - D) / 8;   // 16-byte chunks per row
+    constexpr int NPAD = KPADC + VPADC;
+    for (int c = t; c < 2 * 3 * BKV * NPAD; c += 256) {
+      const int pc = c % NPAD, rest = c / NPAD;
+      const int row = rest % BKV, pl = (rest / BKV) % 3, stage = rest / (3 * BKV);
+      char* base = smem + stage * STAGE;
+      u32x4_t z = {0u, 0u, 0u, 0u};
+      if (pc < KPADC) {
+        *reinterpret_cast<u32x4_t*>(base + pl * KP + row * KS + D * 2 + pc * 16) = z;
+      } else {
+        const int vc = pc - KPADC;
+        if (vc == 0 && pl == 0) z[0] = 0x00003F80u;
+        *reinterpret_cast<u32x4_t*>(base + 3 * KP + pl * VP + row * VS + D * 2 + vc * 16) = z;
+      }
+    }
+  }
+
+  f32x16_t o[NB];
+#pragma unroll
+  for (int i = 0; i < NB; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) o[i][e] = 0.f;
+  float m_run = -1.0e30f;
+
+  int kv_end = p.Skv;
+  if (p.causal) kv_end = min(p.Skv, (int)blockIdx.x * 128 + 128);
+  const int ntiles = (kv_end + BKV - 1) / BKV;
+
+  issue(0);
+  commit(0);
+  __syncthreads();
+  for (int kt = 0; kt < ntiles; ++kt) {
+    const int kv0 = kt * BKV;
+    const char* ks = smem + (kt & 1) * STAGE;
+    const char* vs = ks + 3 * KP;
+    if (kt + 1 < ntiles) issue(kv0 + BKV);
+
+    // S^T = K Q^T (log2 units: Q carries the scale), small terms first
+    f32x16_t s;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) s[e] = 0.f;
+#pragma unroll
+    for (int st = 0; st < NQ; ++st) {
+      const char* ka = ks + r * KS + (16 * st + 8 * h) * 2;
+      const bf16x8_t kh = *reinterpret_cast<const bf16x8_t*>(ka);
+      const bf16x8_t km = *reinterpret_cast<const bf16x8_t*>(ka + KP);
+      const bf16x8_t kl = *reinterpret_cast<const bf16x8_t*>(ka + 2 * KP);
+      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl, qh[st], s, 0, 0, 0);
+      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, ql[st], s, 0, 0, 0);
+      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(km, qm[st], s, 0, 0, 0);
+      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(km, qh[st], s, 0, 0, 0);
+      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qm[st], s, 0, 0, 0);
+      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qh[st], s, 0, 0, 0);
+    }
+
+    // online softmax, lazy reference (moves only when a row outgrows it by 2^RESCALE_THR)
+    if (kv0 + BKV > p.Skv || p.causal) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int key = kv0 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        if (key >= p.Skv || (p.causal && key > qrow)) s[e] = -1.0e30f;
+      }
+    }
+    float mx = -1.0e30f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) mx = fmaxf(mx, s[e]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = mx > m_run + RESCALE_THR ? mx : m_run;
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    m_run = m_new;
+    if (!__all(alpha == 1.0f)) {
+#pragma unroll
+      for (int i = 0; i < NB; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[i][e] *= alpha;
+    }
+    // P^T fragments (B operand): element pairs (e, e+1), three planes
+    u32x4_t ph[2], pm[2], pl[2];
+#pragma unroll
+    for (int st = 0; st < 2; ++st)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float p0 = __builtin_amdgcn_exp2f(s[8 * st + 2 * j] - m_new), p1 = __builtin_amdgcn_exp2f(s[8 * st + 2 * j + 1] - m_new);
+        const Split3 sp = split3_pair(p0, p1);
+        ph[st][j] = sp.h; pm[st][j] = sp.m; pl[st][j] = sp.l;
+      }
+
+    // O^T += V^T P^T; V^T fragments by transpose reads from the bf16 planes (see attn_kernel)
+    {
+      const int g16 = lane >> 4, li = lane & 15;
+      const char* vbase = vs + (4 * (g16 >> 1) + (li >> 2)) * VS + (16 * (g16 & 1) + 4 * (li & 3)) * 2;
+      typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+      auto vfrag = [&](const char* a) {
+        const s16x4_t lo = lds_read_tr16(a), hi = lds_read_tr16(a + 8 * VS);
+        const s16x8_t vv = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        return __builtin_bit_cast(bf16x8_t, vv);
+      };
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+          const char* va = vbase + 16 * st * VS + i * 64;
+          const bf16x8_t vh = vfrag(va), vm = vfrag(va + VP), vl = vfrag(va + 2 * VP);
+          const bf16x8_t Ph = __builtin_bit_cast(bf16x8_t, ph[st]), Pm = __builtin_bit_cast(bf16x8_t, pm[st]), Pl = __builtin_bit_cast(bf16x8_t, pl[st]);
+          o[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, Ph, o[i], 0, 0, 0);
+          o[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, Pl, o[i], 0, 0, 0);
+          o[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vm, Pm, o[i], 0, 0, 0);
+          o[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vm, Ph, o[i], 0, 0, 0);
+          o[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, Pm, o[i], 0, 0, 0);
+          o[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, Ph, o[i], 0, 0, 0);
+        }
+      }
+    }
+
+    if (kt + 1 < ntiles) commit((kt + 1) & 1);
+    __syncthreads();
+  }
+
+  // epilogue: O[q][d] = O^T[d][q] / l, l = O^T[D][q] (the ones column)
+  if (qrow < p.Sq) {
+    const float l = __shfl(o[L_BLK][L_REG], r + 32 * L_HALF, 64);
+    const float inv = 1.0f / l;
+    float* op = (float*)p.O + (size_t)b * p.o_bs + (size_t)qrow * p.o_rs + (size_t)head * D;
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d0 = 32 * i + 8 * g + 4 * h;
+        if (d0 < D) *reinterpret_cast<f32x4_t*>(op + d0) = (f32x4_t){o[i][4 * g] * inv, o[i][4 * g + 1] * inv, o[i][4 * g + 2] * inv, o[i][4 * g + 3] * inv};
+      }
+  }
+}
+
+template <int D>
+static int launch_attn_f32x3(const AttnArgs& a, int B, hipStream_t st) {
+  dim3 grid((a.Sq + 127) / 128, B * a.H);
+  constexpr int lds = 2 * AttnX3Cfg<D>::STAGE;
+  static_assert(lds <= 160 * 1024, "attention f32x3: LDS budget");
+  static std::atomic<unsigned long long> lds_ok{0};
+  if (lds > 48 * 1024 && sd_lds_opt_in(lds_ok, (const void*)attn_f32x3_kernel<D>, lds) != hipSuccess)
+    return sdamd_set_error(2, "attention: cannot reserve %d bytes of LDS", lds);
+  attn_f32x3_kernel<D><<<grid, 256, lds, st>>>(a);
+  SD_LAUNCH_CHECK("attention");
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Flash attention for the VAE's single 512-wide head (decoder.py:39-70 -> attention.py:46-68; S = 4096 at 512^2,
 // 9216 at 768^2).  An O^T accumulator of 512 rows x 32 queries does not fit one wave's registers, so the head dim is
 // split over the workgroup's 4 waves ("split-d accumulators"):
@@ -675,6 +913,12 @@ extern "C" int sdamd_attention(const void* q, const void* k, const void* v, void
   hipStream_t st = (hipStream_t)stream;
   if (d == 512) return dtype == SDAMD_BF16 ? launch_attn512<bf16_t>(a, B, st) : launch_attn512<float>(a, B, st);
   if (d == 40 && dtype == SDAMD_BF16 && a.debug == 17) return launch_attn<bf16_t, 40, true>(a, B, st);
+  { extern int g_f32_emu;
+    if (dtype == SDAMD_F32 && g_f32_emu) {   // sdamd_set_f32_mode: f32 attention on the bf16 matrix pipe (d = 160 keeps the f32 MFMA: registers)
+      if (d == 40) return launch_attn_f32x3<40>(a, B, st);
+      if (d == 64) return launch_attn_f32x3<64>(a, B, st);
+      if (d == 80) return launch_attn_f32x3<80>(a, B, st);
+    } }
 #define ATT(TT) switch (d) { case 40: return launch_attn<TT, 40>(a, B, st); case 64: return launch_attn<TT, 64>(a, B, st); \
                              case 80: return launch_attn<TT, 80>(a, B, st); default: return launch_attn<TT, 160>(a, B, st); }
   if (dtype == SDAMD_BF16) ATT(bf16_t) else ATT(float)

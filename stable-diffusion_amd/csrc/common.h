@@ -28,6 +28,27 @@ __device__ __forceinline__ unsigned pack_bf2(float lo, float hi) {
   return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t_));  // one v_cvt_pk_bf16_f32
 }
 
+// Exact three-term bf16 split of two f32 values, a = hi + mid + lo (8 + 8 + 8 significant bits; each residual is exact
+// in f32): packed pairs for the bf16 MFMA operands of the "bf16x3" f32 paths (gemm_common.h split3_bf16, attention.hip).
+struct Split3 { unsigned h, m, l; };
+__device__ __forceinline__ Split3 split3_pair(float a0, float a1) {
+  Split3 o;
+  o.h = pack_bf2(a0, a1);
+  const float r0 = a0 - __builtin_bit_cast(float, o.h << 16), r1 = a1 - __builtin_bit_cast(float, o.h & 0xffff0000u);
+  o.m = pack_bf2(r0, r1);
+  const float s0 = r0 - __builtin_bit_cast(float, o.m << 16), s1 = r1 - __builtin_bit_cast(float, o.m & 0xffff0000u);
+  o.l = pack_bf2(s0, s1);
+  return o;
+}
+// eight values (two 16-byte f32 chunks) -> the three bf16x8 MFMA operands
+__device__ __forceinline__ void split3_bf16(const f32x4_t a, const f32x4_t b, bf16x8_t& hi, bf16x8_t& mid, bf16x8_t& lo) {
+  const float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+  u32x4_t h, m, l;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) { const Split3 t = split3_pair(v[2 * q], v[2 * q + 1]); h[q] = t.h; m[q] = t.m; l[q] = t.l; }
+  hi = __builtin_bit_cast(bf16x8_t, h); mid = __builtin_bit_cast(bf16x8_t, m); lo = __builtin_bit_cast(bf16x8_t, l);
+}
+
 template <typename T> struct Cvt;
 template <> struct Cvt<float> {
   static __device__ __forceinline__ float ld(const float* p) { return *p; }

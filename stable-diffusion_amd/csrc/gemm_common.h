@@ -50,20 +50,6 @@ template <> struct Cvt<f32e_t> {   // (only reached for f32 outputs: the bf16-ou
   static __device__ __forceinline__ float ld(const f32e_t* p) { return p->v; }
   static __device__ __forceinline__ void st(f32e_t* p, float v) { p->v = v; }
 };
-__device__ __forceinline__ void split3_bf16(const f32x4_t a, const f32x4_t b, bf16x8_t& hi, bf16x8_t& mid, bf16x8_t& lo) {
-  const float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
-  u32x4_t h, m, l;
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const float a0 = v[2 * q], a1 = v[2 * q + 1];
-    const unsigned hp = pack_bf2(a0, a1);
-    const float r0 = a0 - __builtin_bit_cast(float, hp << 16), r1 = a1 - __builtin_bit_cast(float, hp & 0xffff0000u);
-    const unsigned mp = pack_bf2(r0, r1);
-    const float s0 = r0 - __builtin_bit_cast(float, mp << 16), s1 = r1 - __builtin_bit_cast(float, mp & 0xffff0000u);
-    h[q] = hp; m[q] = mp; l[q] = pack_bf2(s0, s1);
-  }
-  hi = __builtin_bit_cast(bf16x8_t, h); mid = __builtin_bit_cast(bf16x8_t, m); lo = __builtin_bit_cast(bf16x8_t, l);
-}
 #endif
 
 // gemm2.hip: 8-wave, LDS-DMA-staged kernels (bf16 and exact-f32 MFMA).  Returns -1 when no tile configuration of that

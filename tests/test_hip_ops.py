@@ -658,6 +658,29 @@ def test_f32_modes_against_float64(impl):
     assert err["exact"][2] < 5e-6 and err["bf16x3"][2] <= 1.25 * err["exact"][2], err
 
 
+@pytest.mark.parametrize("B,H,d,Sq,Skv,causal", [(2, 8, 40, 1024, 1024, False), (1, 8, 80, 512, 512, False), (2, 8, 40, 300, 77, False),
+                                                  (2, 12, 64, 77, 77, True), (1, 8, 160, 256, 256, False)])
+def test_f32_attention_modes_against_float64(B, H, d, Sq, Skv, causal):
+    """attention.py:46-68 in fp32: the default kernel (attn_f32x3_kernel: Q, K, V and P split into three bf16 terms, six
+    MFMA products each) and the exact f32-MFMA kernel against float64 softmax(QK^T/sqrt(d))V, scores spread over +-12.
+    d = 160 has no bf16x3 kernel (both modes run the exact one)."""
+    g = torch.Generator().manual_seed(11)
+    C = H * d
+    qq, kk, vv = torch.randn(B, Sq, C, generator=g) * 3.0, torch.randn(B, Skv, C, generator=g), torch.randn(B, Skv, C, generator=g)
+    hd = lambda x, S: x.double().view(B, S, H, d).transpose(1, 2)
+    ref = F.scaled_dot_product_attention(hd(qq, Sq), hd(kk, Skv), hd(vv, Skv), is_causal=causal).transpose(1, 2).reshape(B, Sq, C)
+    err = {}
+    old = ops.get_f32_mode()
+    try:
+        for mode in ("exact", "bf16x3"):
+            ops.set_f32_mode(mode)
+            out = ops.attention(qq.to(DEV), kk.to(DEV), vv.to(DEV), H, causal=causal).double().cpu()
+            err[mode] = float((out - ref).norm() / ref.norm())
+    finally:
+        ops.set_f32_mode(old)
+    assert err["exact"] < 5e-6 and err["bf16x3"] <= 1.25 * err["exact"] + 1e-8, err
+
+
 def test_argument_errors_are_reported():
     from sd_amd import _lib
     a = torch.zeros((4, 100), device=DEV)
