@@ -334,10 +334,19 @@ def run(args):
         extra["unet_step_ms_bf16_b2"] = round(unet_step_ms(j1.loop, j1.latents0), 3)
         del j1
         engine.set_compute_dtype(models["diffusion"], torch.float32)
-        j2 = Txt2ImgJob(models, 0, 1, args.denoise_steps, 7.5, device)
-        extra["unet_step_ms_fp32_b2"] = round(unet_step_ms(j2.loop, j2.latents0), 3)
+        # fp32 operands, both ways of reaching the matrix cores (include/sdamd.h sdamd_set_f32_mode): the default forms
+        # each f32 product from three-term bf16 splits (six bf16 MFMAs, f32 accumulate; as close to float64 as the f32
+        # MFMA, tests/test_hip_ops.py::test_f32_modes_against_float64), "exact" is v_mfma_f32_16x16x4_f32
+        for mode, key in (("bf16x3", "unet_step_ms_fp32_b2"), ("exact", "unet_step_ms_fp32_b2_exact_mfma")):
+            ops.set_f32_mode(mode)
+            j2 = Txt2ImgJob(models, 0, 1, args.denoise_steps, 7.5, device)   # (a captured loop keeps the mode it was captured under)
+            extra[key] = round(unet_step_ms(j2.loop, j2.latents0), 3)
+            del j2
+        ops.set_f32_mode("bf16x3")
         extra["unet_step_fp32_b2_tflops"] = round(1.6065 / (extra["unet_step_ms_fp32_b2"] * 1e-3), 1)
-        del j2
+        extra["unet_step_fp32_b2_note"] = ("BASELINE config 2 (UNET step, latent 64x64x4, batch 2 = CFG, fp32 tensors): f32 in / f32 out / f32 "
+                                           "accumulate; operands split exactly into 3 bf16 terms in registers, 6 MFMA products per f32 product; "
+                                           "_exact_mfma = the same step on the f32 MFMA instruction (157 TFLOP/s peak)")
         engine.set_compute_dtype(models["diffusion"], dtype)
     if cpu_sd:
         result["cpu_baseline"] = cpu_baseline_leg(cpu_sd)

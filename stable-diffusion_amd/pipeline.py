@@ -183,7 +183,7 @@ def _denoise_loop(diffusion, context, timesteps, coef, noise, latents, cfg_scale
     if not use_graph:
         return DenoiseLoop(diffusion, context, timesteps, coef, noise, latents, cfg_scale, do_cfg, False)
     key = (id(diffusion), diffusion.compute_dtype, tuple(latents.shape), str(latents.device), len(timesteps), bool(do_cfg),
-           float(cfg_scale), noise is None)
+           float(cfg_scale), noise is None, ops.get_f32_mode())   # (a captured graph keeps the f32 mode it was captured under)
     ent = _LOOP_CACHE.get(key)
     stamp = _weights_stamp(diffusion)
     if ent is not None and ent[0] == stamp and ent[1].rebind(context, timesteps, coef, noise, latents):
