@@ -28,11 +28,13 @@ for M, N, K, res in [(8192, 320, 320, True), (2048, 640, 640, True), (512, 1280,
     r = rnd(M, N) if res else None
     ref = a.double() @ w.double().t() + (r.double() if res else 0)
     row = []
-    for on in (False, True):
-        emu(on)
+    for on, pl in ((False, False), (True, False), (True, True)):
+        emu(on); ops.USE_WEIGHT_PLANES = pl
         out = ops.gemm(a, w, None, r)
+        if pl: assert torch.equal(out, prev), float((out - prev).abs().max())
+        prev = out
         ms = t(lambda: ops.gemm(a, w, None, r))
-        row.append(f"{'bf16x3' if on else 'exact '} {ms*1e3:6.1f}us {2.0*M*N*K/ms/1e9:4.0f}TF err {rel(out, ref):.1e}")
+        row.append(f"{('x3+planes' if pl else 'bf16x3') if on else 'exact '} {ms*1e3:6.1f}us {2.0*M*N*K/ms/1e9:4.0f}TF err {rel(out, ref):.1e}")
     print(f"  M{M} N{N} K{K} res={int(res)}  " + " | ".join(row), flush=True)
 print("conv f32")
 for B, H, Cin, Cout, res in [(2, 8, 1280, 1280, True), (2, 16, 1280, 1280, True), (2, 32, 640, 640, True), (2, 64, 320, 320, True), (2, 64, 640, 320, False),
@@ -42,10 +44,12 @@ for B, H, Cin, Cout, res in [(2, 8, 1280, 1280, True), (2, 16, 1280, 1280, True)
     ref = torch.nn.functional.conv2d(x.double().permute(0, 3, 1, 2), w.double().view(Cout, 3, 3, Cin).permute(0, 3, 1, 2), b.double(), padding=1).permute(0, 2, 3, 1)
     if res: ref = ref + r.double()
     row = []
-    for on in (False, True):
-        emu(on)
+    for on, pl in ((False, False), (True, False), (True, True)):
+        emu(on); ops.USE_WEIGHT_PLANES = pl
         out = ops.conv3x3(x, w, b, r, 1, 0, False)
+        if pl: assert torch.equal(out, prev), float((out - prev).abs().max())
+        prev = out
         ms = t(lambda: ops.conv3x3(x, w, b, r, 1, 0, False))
-        row.append(f"{'bf16x3' if on else 'exact '} {ms*1e3:6.1f}us {2.0*B*H*H*Cout*9*Cin/ms/1e9:4.0f}TF err {rel(out, ref):.1e}")
+        row.append(f"{('x3+planes' if pl else 'bf16x3') if on else 'exact '} {ms*1e3:6.1f}us {2.0*B*H*H*Cout*9*Cin/ms/1e9:4.0f}TF err {rel(out, ref):.1e}")
     print(f"  B{B} H{H} {Cin}->{Cout} res={int(res)}  " + " | ".join(row), flush=True)
 emu(True)

@@ -153,12 +153,19 @@ int sdamd_vae_sample(const float* x, const float* noise, float* out, const float
  * colstats[(rb*N + n)*2 + {0,1}] = sum and sum of squares of the stored C[rb*64..rb*64+63][n] (f32,
  * ceil(M/64)*N*2 floats) for a GroupNorm that normalises C (sdamd_groupnorm_nhwc_pre).  Only un-split, un-batched
  * launches on the LDS-DMA kernels with f32 or operand-type output produce them: *colstats_written (host int, may
- * be null) says whether this call did. */
+ * be null) says whether this call did.
+ * `w_planes` (may be null; f32 operands in the bf16x3 mode only): W split ahead of time by sdamd_split3_weights
+ * (packed per batch entry); the kernels that take it then split only the activation fragments in registers. */
 int sdamd_gemm(const void* A, const void* W, void* C, const float* bias, const void* residual, int M,
                int N, int K, int lda, int ldw, int ldc, int ldr, int batch, long long strideA,
                long long strideW, long long strideC, long long strideR, int act, int dtype,
                int out_f32, void* ws, size_t ws_bytes, float* colstats, int* colstats_written,
-               void* stream);
+               const void* w_planes, void* stream);
+/* The weights of an f32 Linear / Conv2d (rows x K, K % 32 == 0, row stride ldw), split once into the three bf16
+ * terms of the bf16x3 mode (sdamd_set_f32_mode): planes [rows][K/32][hi | mid | lo][32] bf16 = 6 bytes per weight,
+ * the 32 k of a K-tile in the order the kernels' MFMA fragments take them.  No reference counterpart (a weight
+ * preparation step like the reference's .half() of its parameters, pipeline.py:44-49). */
+int sdamd_split3_weights(const float* w, void* planes, long long rows, int K, int ldw, void* stream);
 /* block tile the GEMM/conv launcher picks for a problem (BM*1000+BN + 1000000*(splits-1)); host-only helper
  * used by bench.py to attribute launches to kernel instantiations (no reference counterpart) */
 int sdamd_gemm_tile(int M, int N, int K, int batch, int dtype, size_t ws_bytes, int act);
@@ -189,7 +196,7 @@ int sdamd_set_f32_mode(int mode);
 int sdamd_conv3x3(const void* x, const void* w, void* y, const float* bias, const void* residual,
                   int B, int H, int W, int Cin, int Cout, int stride, int pad_mode, int upsample,
                   int act, int dtype, int out_f32, void* ws, size_t ws_bytes, float* colstats,
-                  int* colstats_written, void* stream);
+                  int* colstats_written, const void* w_planes, void* stream);
 /* first convs (diffusion.py:196, decoder.py:78, encoder.py:10): x NCHW f32 [B], Cin 3|4,
  * w [ky][kx][Cin][Cout] f32 -> y NHWC dtype [copies*B]: sample n is written `copies` times, at
  * n, n+B, ... (copies = 2: the UNet input under classifier-free guidance is the same latents

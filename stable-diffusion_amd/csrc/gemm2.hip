@@ -63,7 +63,12 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
 template <typename T, int BM, int BN, int WGM, int WGN, int STAGES, bool CONV, int EPI>
 __global__ __launch_bounds__(WGM* WGN * 64) void gemm2_kernel(const GemmArgs p) {
   constexpr bool F32 = sizeof(T) == 4;     // exact-f32 MFMA (v_mfma_f32_16x16x4_f32) on f32 operands
-  constexpr bool EMU = std::is_same<T, f32e_t>::value;   // f32 operands split into 3 bf16 terms, 6 bf16 MFMAs (see split3_bf16)
+  // f32 operands split into 3 bf16 terms, 6 bf16 MFMAs (split3_bf16).  WPL: the weight operand arrives split already
+  // (GemmArgs::W3, three bf16 planes of 32 k = 64 bytes per row and K-tile), so only the activation fragments are split
+  // in registers: TM instead of TM + TN fragment splits per K-tile (4 of 9 on the 128x160 tile, 2 of 7 on 64x160).
+  constexpr bool WPL = std::is_same<T, f32w_t>::value;
+  constexpr bool EMU = std::is_same<T, f32e_t>::value || WPL;
+  typedef typename std::conditional<WPL, bf16_t, T>::type TW;   // element type behind the W pointers
   constexpr int EPC = 16 / sizeof(T);      // elements per 16-byte chunk
   constexpr int BKE = 8 * EPC;             // K elements per 128-byte tile row (64 bf16 / 32 f32)
   constexpr int NW = WGM * WGN;
@@ -71,11 +76,12 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm2_kernel(const GemmArgs p) 
   constexpr int TM = WTM / 16, TN = WTN / 16;    // 16x16 MFMA tiles per wave
   // 1-KiB DMA pieces (8 rows) per K-tile: piece g of A (or B) belongs to wave g % NW; when the
   // piece count does not divide, the last round is predicated on the (scalar) wave id
-  constexpr int A_PIECES = BM / 8, B_PIECES = BN / 8;
+  // (WPL: a 1-KiB piece of W is 16 rows x 64 bytes of one plane; plane p of 16-row block b is piece p*BN/16 + b)
+  constexpr int A_PIECES = BM / 8, B_PIECES = WPL ? 3 * (BN / 16) : BN / 8;
   constexpr int A_INS = (A_PIECES + NW - 1) / NW, B_INS = (B_PIECES + NW - 1) / NW;
   constexpr int MIN_PIECES = A_PIECES / NW + B_PIECES / NW;   // fewest pieces any wave issues per tile
   constexpr int NPIECE = A_INS + B_INS;
-  constexpr int STAGE = (BM + BN) * 128;
+  constexpr int STAGE = BM * 128 + B_PIECES * 1024;
   static_assert(BM % 8 == 0 && BN % 8 == 0 && WTM % 16 == 0 && WTN % 16 == 0 && STAGES >= 2 && STAGES <= 4, "tile shape");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -90,7 +96,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm2_kernel(const GemmArgs p) 
   const int m0 = tm * BM, n0 = tn * BN;
   const int batch = blockIdx.y;   // (split-K launches have batch == 1 and use blockIdx.z = split)
   const T* __restrict__ A = (const T*)p.A + (size_t)batch * p.sA;
-  const T* __restrict__ W = (const T*)p.W + (size_t)batch * p.sW;
+  const TW* __restrict__ W = (const TW*)p.W + (size_t)batch * p.sW * (WPL ? 3 : 1);
   // Phase-decomposed upsample conv (CONV, p.phase_up): "batch" is the output phase (py, px).  Output
   // pixel (2y+py, 2x+px) of conv3x3(nearest2x(in)) only sees the 2x2 input window starting at
   // (y-(1-py), x-(1-px)), with the 3x3 taps that land on the same input pixel pre-summed on the host:
@@ -113,12 +119,22 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm2_kernel(const GemmArgs p) 
   const int rr = lane >> 3, cl = lane & 7;
 
   // per-lane DMA sources: piece i of this wave covers tile rows (wave + NW*i)*8 .. +7
-  const T* wsrc[B_INS];
+  const TW* wsrc[B_INS];
 #pragma unroll
   for (int i = 0; i < B_INS; ++i) {
-    const int row = min(wave + NW * i, B_PIECES - 1) * 8 + rr;
-    const int n = min(n0 + row, p.N - 1);
-    wsrc[i] = W + (size_t)n * p.ldw + (cl ^ ((row >> 1) & 7)) * EPC;
+    if constexpr (WPL) {
+      // lane l of a piece: row l>>2 of the 16-row block, 16-byte chunk l&3 of the 64-byte plane row; the chunk index is
+      // swizzled with (row>>2)&3 on the source so that the 16 rows a ds_read_b128 lane group touches cover all banks
+      const int g = min(wave + NW * i, B_PIECES - 1);
+      const int plane = g / (BN / 16), blk = g - plane * (BN / 16);
+      const int row = blk * 16 + (lane >> 2);
+      const int n = min(n0 + row, p.N - 1);
+      wsrc[i] = W + (size_t)n * 3 * p.K + plane * 32 + (((lane & 3) ^ ((row >> 2) & 3)) * 8);
+    } else {
+      const int row = min(wave + NW * i, B_PIECES - 1) * 8 + rr;
+      const int n = min(n0 + row, p.N - 1);
+      wsrc[i] = W + (size_t)n * p.ldw + (cl ^ ((row >> 1) & 7)) * EPC;
+    }
   }
   // A sources.  Dense: row pointer (+ swizzled chunk).  Conv: pointer to the top-left tap of the pixel's window
   // (may lie outside the image) + a bit mask of the taps that are inside: per K-tile the gather address is then
@@ -165,6 +181,9 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm2_kernel(const GemmArgs p) 
     if constexpr (PI < A_INS) {
       constexpr int i = PI;
       if (A_PIECES % NW != 0 && i == A_INS - 1 && wave + NW * i >= A_PIECES) return;
+#ifdef SDAMD_FILL_ABLATE   // timing experiment (wrong results): the activation tile is only fetched for tap (0, 0) = A fill / 9
+      if (CONV && p.debug == 3 && (ky | kx)) return;
+#endif
       const T* g;
       if (CONV) {
         const int delta = __builtin_amdgcn_readfirstlane((ky * p.Wd + kx) * p.Cin + cc);   // wave-uniform
@@ -176,7 +195,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm2_kernel(const GemmArgs p) 
     } else {
       constexpr int i = PI - A_INS;
       if (B_PIECES % NW != 0 && i == B_INS - 1 && wave + NW * i >= B_PIECES) return;
-      __builtin_amdgcn_global_load_lds((gbl_void_t*)(wsrc[i] + k0), (lds_void_t*)(stage + BM * 128 + (wave + NW * i) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)(wsrc[i] + k0 * (WPL ? 3 : 1)), (lds_void_t*)(stage + BM * 128 + (wave + NW * i) * 1024), 16, 0, 0);
     }
   };
   auto advance_k = [&]() { if (CONV) { cc += BKE; if (cc >= p.Cin) { cc = 0; ++tap; } } };
@@ -241,21 +260,35 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm2_kernel(const GemmArgs p) 
       __builtin_amdgcn_sched_group_barrier(0x008, NMF - PER * NRD, 0);
     }
     if constexpr (EMU) {
-      load_frags(0);
-      load_frags(1);
+      if constexpr (WPL) {
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+          for (int i = 0; i < TM; ++i) xf[g][i] = *reinterpret_cast<const frag_t*>(sa + swz2(wm * WTM + i * 16 + r16, 4 * g + q4));
+      } else {
+        load_frags(0);
+        load_frags(1);
+      }
       bf16x8_t xh[TM], xm[TM], xl[TM];
 #pragma unroll
       for (int i = 0; i < TM; ++i) split3_bf16(xf[0][i], xf[1][i], xh[i], xm[i], xl[i]);
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
-        bf16x8_t wh, wm, wl;
-        split3_bf16(wf[0][j], wf[1][j], wh, wm, wl);
+        bf16x8_t wh, wmid, wl;
+        if constexpr (WPL) {   // (sdamd_split3_weights stores the 32 k of a tile in the fragment order of the f32 reads)
+          const char* wb = sw + ((wn * WTN + j * 16) >> 4) * 1024 + r16 * 64 + ((q4 ^ ((r16 >> 2) & 3)) << 4);
+          wh = *reinterpret_cast<const bf16x8_t*>(wb);
+          wmid = *reinterpret_cast<const bf16x8_t*>(wb + (BN / 16) * 1024);
+          wl = *reinterpret_cast<const bf16x8_t*>(wb + 2 * (BN / 16) * 1024);
+        } else {
+          split3_bf16(wf[0][j], wf[1][j], wh, wmid, wl);
+        }
 #pragma unroll
         for (int i = 0; i < TM; ++i) {   // small terms first
           acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, xh[i], acc[j][i], 0, 0, 0);
           acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xl[i], acc[j][i], 0, 0, 0);
-          acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, xm[i], acc[j][i], 0, 0, 0);
-          acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, xh[i], acc[j][i], 0, 0, 0);
+          acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wmid, xm[i], acc[j][i], 0, 0, 0);
+          acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wmid, xh[i], acc[j][i], 0, 0, 0);
           acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xm[i], acc[j][i], 0, 0, 0);
           acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh[i], acc[j][i], 0, 0, 0);
         }
@@ -651,7 +684,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
 
 template <typename T, int BM, int BN, int WGM, int WGN, int STAGES, bool CONV, int EPI>
 static int launch2_epi(GemmArgs& a, int batch, hipStream_t st) {
-  constexpr int lds = STAGES * (BM + BN) * 128;
+  constexpr int lds = STAGES * (BM * 128 + (std::is_same<T, f32w_t>::value ? BN * 192 : BN * 128));
+  static_assert(lds <= 160 * 1024, "gemm2: LDS budget");
   static std::atomic<unsigned long long> lds_ok{0};
   if (sd_lds_opt_in(lds_ok, (const void*)gemm2_kernel<T, BM, BN, WGM, WGN, STAGES, CONV, EPI>, lds) != hipSuccess)
     return sdamd_set_error(2, "gemm2: cannot reserve %d bytes of LDS", lds);
@@ -786,6 +820,18 @@ static int launch_gemm2_t(GemmArgs& a, int batch, bool conv, int mode, hipStream
     tile = g_gemm_debug == 6 ? 128128 : 256256;
     a.splits = 1;
   }
+  if constexpr (std::is_same<T, f32w_t>::value) {   // 2 x (BM*128 + BN*192) bytes of LDS: 64x160 two workgroups per CU, the others one
+    switch (tile) {
+      case 128160:
+        // (92 KB of LDS: one workgroup per CU.  Only where the launch has no second workgroup per CU to lose:
+        //  M 8192 N 960 K 320, 384 workgroups, measured 44.9 us with in-register weight splits, 49.9 us with planes)
+        if ((long long)((a.M + 127) / 128) * ((a.N + 159) / 160) * batch * a.splits > 256) { a.splits = 1; return -1; }
+        return conv ? launch2<T, 128, 160, 2, 2, 2, true>(a, batch, st) : launch2<T, 128, 160, 2, 2, 2, false>(a, batch, st);
+      case 64160: return conv ? launch2<T, 64, 160, 2, 2, 2, true>(a, batch, st) : launch2<T, 64, 160, 2, 2, 2, false>(a, batch, st);
+      case 128320: return conv ? launch2<T, 128, 320, 2, 4, 2, true>(a, batch, st) : launch2<T, 128, 320, 2, 4, 2, false>(a, batch, st);
+      default: a.splits = 1; return -1;
+    }
+  } else
   switch (tile) {
     case 128128: return conv ? -1 : launch2<T, 128, 128, 2, 2, 2, false>(a, batch, st);
     case 128160:
@@ -805,6 +851,14 @@ static int launch_gemm2_t(GemmArgs& a, int batch, bool conv, int mode, hipStream
 
 int launch_gemm2(GemmArgs& a, int dtype, int batch, bool conv, int mode, hipStream_t st) {
   extern int g_f32_emu;
-  if (dtype != SDAMD_BF16 && g_f32_emu) return launch_gemm2_t<f32e_t>(a, batch, conv, mode, st);
+  if (dtype != SDAMD_BF16 && g_f32_emu) {
+    if (a.W3 && (batch == 1 || a.sW == (long long)a.N * a.K)) {   // pre-split weight planes (packed per batch entry)
+      GemmArgs b = a;
+      b.W = a.W3;
+      const int r = launch_gemm2_t<f32w_t>(b, batch, conv, mode, st);
+      if (r >= 0) { a.splits = b.splits; a.colstats_done = b.colstats_done; return r; }
+    }
+    return launch_gemm2_t<f32e_t>(a, batch, conv, mode, st);
+  }
   return dtype == SDAMD_BF16 ? launch_gemm2_t<bf16_t>(a, batch, conv, mode, st) : launch_gemm2_t<float>(a, batch, conv, mode, st);
 }

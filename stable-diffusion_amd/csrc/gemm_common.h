@@ -10,6 +10,7 @@
 struct GemmArgs {
   const void* A;     // dense: [M][lda]; conv: NHWC input [B][H][W][Cin]
   const void* W;     // [N][ldw], K-contiguous (conv: [Cout][ky][kx][Cin])
+  const void* W3;    // f32 operands only, optional: W pre-split into bf16 planes [N][K/32][hi|mid|lo][32] (sdamd_split3_weights), packed
   void* C;           // [M][ldc]
   const float* bias; // [N] or null
   const void* R;     // residual [M][ldr] (same dtype as C: f32 when out_f32, else the operand dtype) or null
@@ -46,6 +47,8 @@ struct GemmArgs {
 // is done on the fragments in registers (11 VALU per element pair).  Non-finite inputs give NaN (inf - inf in the
 // residual) where the exact kernel would give inf.
 struct f32e_t { float v; };
+// as f32e_t, with the WEIGHT operand split ahead of time (sdamd_split3_weights): W points to bf16 planes, see gemm2.hip
+struct f32w_t { float v; };
 template <> struct Cvt<f32e_t> {   // (only reached for f32 outputs: the bf16-output branches are dead for 4-byte operands)
   static __device__ __forceinline__ float ld(const f32e_t* p) { return p->v; }
   static __device__ __forceinline__ void st(f32e_t* p, float v) { p->v = v; }

@@ -434,6 +434,33 @@ int g_f32_emu = 1;
 extern "C" int sdamd_set_f32_mode(int mode) { int old = g_f32_emu; if (mode == 0 || mode == 1) g_f32_emu = mode; return old; }
 extern "C" int sdamd_set_gemm_impl(int impl) { int old = g_gemm_impl; g_gemm_impl = impl & 255; g_gemm_debug = impl >> 8; return old; }
 
+// Weights of an f32 GEMM / conv3x3, split once into the three bf16 terms of the bf16x3 mode (common.h split3_pair):
+// planes[row][k/32][hi|mid|lo][32], the 32 k of a K-tile stored in the order the MFMA fragments of the f32 activation
+// operand take them (16-byte chunk q holds k = 4q..4q+3 and 16+4q..16+4q+3), so a kernel reads ready operands.
+__global__ __launch_bounds__(256) void split3_weights_kernel(const float* __restrict__ w, unsigned* __restrict__ planes, long long rows,
+                                                             int K, int ldw) {
+  const long long pairs = rows * (K >> 1);
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < pairs; idx += (long long)gridDim.x * 256) {
+    const long long row = idx / (K >> 1);
+    const int k = (int)(idx - row * (K >> 1)) * 2;
+    const float* src = w + row * ldw + k;
+    const Split3 t = split3_pair(src[0], src[1]);
+    const int kt = k >> 5, kk = k & 31;
+    const int slot = ((kk & 15) >> 2) * 8 + (kk >> 4) * 4 + (kk & 3);      // even, with slot + 1 = the pair's second value
+    unsigned* dst = planes + (row * 3 * K + (long long)kt * 96 + slot) / 2;
+    dst[0] = t.h; dst[16] = t.m; dst[32] = t.l;
+  }
+}
+extern "C" int sdamd_split3_weights(const float* w, void* planes, long long rows, int K, int ldw, void* stream) {
+  SD_CHECK(w && planes && rows > 0 && K > 0 && K % 32 == 0 && ldw >= K && ldw % 2 == 0, "split3_weights: rows=%lld K=%d ldw=%d", rows, K, ldw);
+  SD_CHECK(((uintptr_t)w % 8) == 0 && ((uintptr_t)planes % 16) == 0, "split3_weights: alignment");
+  const long long pairs = rows * (K >> 1);
+  const int g = (int)((pairs + 255) / 256 > 4096 ? 4096 : (pairs + 255) / 256);
+  split3_weights_kernel<<<g, 256, 0, (hipStream_t)stream>>>(w, (unsigned*)planes, rows, K, ldw);
+  SD_LAUNCH_CHECK("split3_weights");
+  return 0;
+}
+
 // 1 when sdamd_gemm can run `act` fused for this dtype / N with the current kernel family selection
 extern "C" int sdamd_gemm_supports_act(int act, int dtype, int N) {
   if (act != ACT_GEGLU) return act >= ACT_NONE && act <= ACT_SILU;
@@ -475,12 +502,12 @@ static int check_common(const GemmArgs& a, int dtype, const char* what) {
 extern "C" int sdamd_gemm(const void* A, const void* W, void* C, const float* bias, const void* residual, int M, int N, int K,
                           int lda, int ldw, int ldc, int ldr, int batch, long long strideA, long long strideW,
                           long long strideC, long long strideR, int act, int dtype, int out_f32, void* ws,
-                          size_t ws_bytes, float* colstats, int* colstats_written, void* stream) {
+                          size_t ws_bytes, float* colstats, int* colstats_written, const void* w_planes, void* stream) {
   if (colstats_written) *colstats_written = 0;
   GemmArgs a = {};
   a.colstats = colstats;
   a.splits = 1; a.ws = (float*)ws; a.ws_bytes = ws_bytes; a.debug = g_gemm_debug;
-  a.A = A; a.W = W; a.C = C; a.bias = bias; a.R = residual;
+  a.A = A; a.W = W; a.W3 = dtype == SDAMD_F32 ? w_planes : nullptr; a.C = C; a.bias = bias; a.R = residual;
   a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldw = ldw; a.ldc = ldc; a.ldr = ldr;
   a.sA = strideA; a.sW = strideW; a.sC = strideC; a.sR = strideR;
   a.act = act; a.out_f32 = out_f32;
@@ -507,8 +534,10 @@ extern "C" int sdamd_gemm(const void* A, const void* W, void* C, const float* bi
 // upsample=1 reads the input through a nearest 2x upsample (diffusion.py:148-150, decoder.py:90-111).
 extern "C" int sdamd_conv3x3(const void* x, const void* w, void* y, const float* bias, const void* residual, int B, int H,
                              int Wd, int Cin, int Cout, int stride, int pad_mode, int upsample, int act, int dtype,
-                             int out_f32, void* ws, size_t ws_bytes, float* colstats, int* colstats_written, void* stream) {
+                             int out_f32, void* ws, size_t ws_bytes, float* colstats, int* colstats_written, const void* w_planes,
+                             void* stream) {
   if (colstats_written) *colstats_written = 0;
+  if (dtype != SDAMD_F32) w_planes = nullptr;
   SD_CHECK(stride == 1 || stride == 2, "conv3x3: stride=%d", stride);
   SD_CHECK(pad_mode == 0 || pad_mode == 1, "conv3x3: pad_mode=%d", pad_mode);
   SD_CHECK(upsample >= 0 && upsample <= 2, "conv3x3: upsample=%d", upsample);
@@ -521,7 +550,7 @@ extern "C" int sdamd_conv3x3(const void* x, const void* w, void* y, const float*
              "conv3x3: the phase-decomposed upsample form needs the 8-wave kernels, stride 1, pad 1, no residual");
     SD_CHECK(Cin % (dtype == SDAMD_BF16 ? 64 : 32) == 0, "conv3x3: Cin=%d must be a multiple of the K-tile", Cin);
     GemmArgs a = {};
-    a.A = x; a.W = w; a.C = y; a.bias = bias; a.R = nullptr;
+    a.A = x; a.W = w; a.W3 = w_planes; a.C = y; a.bias = bias; a.R = nullptr;
     a.M = B * H * Wd; a.N = Cout; a.K = 4 * Cin;
     a.lda = 0; a.ldw = 4 * Cin; a.ldc = Cout; a.ldr = Cout;
     a.sA = 0; a.sW = (long long)Cout * 4 * Cin; a.sC = 0; a.sR = 0;
@@ -540,6 +569,7 @@ extern "C" int sdamd_conv3x3(const void* x, const void* w, void* y, const float*
         for (int ph = 0; ph < 4; ++ph) {
           GemmArgs b = a;
           b.W = (const char*)w + (size_t)ph * a.sW * esz;
+          if (w_planes) b.W3 = (const char*)w_planes + (size_t)ph * a.sW * 3 * 2;
           b.phase_base = ph;
           b.ws = (float*)ws; b.ws_bytes = ws_bytes;
           const int r = launch_gemm2(b, dtype, 1, true, g_gemm_impl, st);
@@ -559,7 +589,7 @@ extern "C" int sdamd_conv3x3(const void* x, const void* w, void* y, const float*
   const int Ho = pad_mode == 0 ? (Hin + 2 - 3) / stride + 1 : (Hin + 1 - 3) / stride + 1;
   const int Wo = pad_mode == 0 ? (Win + 2 - 3) / stride + 1 : (Win + 1 - 3) / stride + 1;
   GemmArgs a = {};
-  a.A = x; a.W = w; a.C = y; a.bias = bias; a.R = residual;
+  a.A = x; a.W = w; a.W3 = w_planes; a.C = y; a.bias = bias; a.R = residual;
   a.M = B * Ho * Wo; a.N = Cout; a.K = 9 * Cin;
   a.lda = 0; a.ldw = 9 * Cin; a.ldc = Cout; a.ldr = Cout;
   a.act = act; a.out_f32 = out_f32;

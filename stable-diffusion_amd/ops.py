@@ -476,11 +476,12 @@ def gemm(a, w, bias=None, residual=None, act=ACT_NONE, out_f32=False, out_hilo=F
     ws = _gemm_workspace(a.device)
     nbytes = (M * K + N * K) * a.element_size() + out.numel() * out.element_size() + (0 if residual is None else residual.numel() * residual.element_size())
     stats, wrote = _stats_request(want_stats and act != ACT_GEGLU and not out_hilo, M, N, a.device)
+    w3 = weight_planes(w)
     _timed(lambda: f"gemm_{_dt(a.dtype)}_{_tile_tag(M, N, K, a.dtype, ws, 1, act, residual is not None and res_dtype == torch.float32)}",
            2.0 * M * N * (K if flops_k is None else flops_k),
            lambda: _lib.check(_lib.lib().sdamd_gemm(_p(a), _p(w), _p(out), _p(bias), _p(residual), M, N, K, lda, K, n_out, ldr, 1,
                                                     0, 0, 0, 0, int(act), _code(a.dtype), int(out_f32), _p(ws), ws.numel(),
-                                                    _p(stats), wrote, _stream())),
+                                                    _p(stats), wrote, _p(w3), _stream())),
            lambda: f"M{M} N{N} K{K}{' +res' if residual is not None else ''}{' hilo' if out_f32 == 2 else ' f32out' if out_f32 else ''}{' geglu' if act == ACT_GEGLU else ''}",
            nbytes)
     _stats_attach(out, stats, wrote)
@@ -500,6 +501,29 @@ def _stats_attach(out, stats, wrote):
 
 
 F32_MODES = {"exact": 0, "bf16x3": 1}
+USE_WEIGHT_PLANES = True      # tests / A-B switch: False makes the bf16x3 kernels split the weight fragments in registers
+_W3 = {}                      # data_ptr -> (weakref to the f32 weight, its version, shape, bf16 planes)
+
+
+def weight_planes(w):
+    """The bf16x3 planes of a contiguous f32 weight matrix [..., K] (sdamd_split3_weights: [rows][K/32][hi|mid|lo][32]
+    bf16), made once per weight tensor and kept while that tensor lives; None when the mode / shape has no use for them.
+    Never made under graph capture (the warm-up run before a capture makes them)."""
+    if not USE_WEIGHT_PLANES or w.dtype != torch.float32 or not w.is_contiguous() or w.shape[-1] % 32 or get_f32_mode() != "bf16x3":
+        return None
+    key = w.data_ptr()
+    ent = _W3.get(key)
+    if ent is not None and ent[0]() is w and ent[1] == w._version and ent[2] == tuple(w.shape):
+        return ent[3]
+    if torch.cuda.is_current_stream_capturing():
+        raise _lib.SdamdError("weight planes requested for the first time under graph capture: run the step once before capturing")
+    K = w.shape[-1]
+    rows = w.numel() // K
+    planes = torch.empty((rows, 3 * K), dtype=torch.bfloat16, device=w.device)
+    _lib.check(_lib.lib().sdamd_split3_weights(_p(w), _p(planes), rows, K, K, _stream()))
+    import weakref
+    _W3[key] = (weakref.ref(w, lambda _r, k=key: _W3.pop(k, None)), w._version, tuple(w.shape), planes)
+    return planes
 
 
 def set_f32_mode(mode):
@@ -536,7 +560,7 @@ def bmm_nt(a, b, out_f32=False):
     assert b.shape[0] == Bt and b.shape[2] == K
     out = torch.empty((Bt, M, N), dtype=torch.float32 if out_f32 else a.dtype, device=a.device)
     _lib.check(_lib.lib().sdamd_gemm(_p(a), _p(b), _p(out), 0, 0, M, N, K, a.stride(1), b.stride(1), N, 0, Bt, a.stride(0),
-                                     b.stride(0), M * N, 0, ACT_NONE, _code(a.dtype), int(out_f32), 0, 0, 0, None, _stream()))
+                                     b.stride(0), M * N, 0, ACT_NONE, _code(a.dtype), int(out_f32), 0, 0, 0, None, 0, _stream()))
     return out
 
 
@@ -569,12 +593,13 @@ def conv3x3(x, w, bias, residual=None, stride=1, pad_mode=0, upsample=False, act
     ws = _gemm_workspace(x.device)
     nbytes = (x.numel() + w.numel()) * x.element_size() + out.numel() * out.element_size() * (1 if residual is None else 2)
     stats, wrote = _stats_request(want_stats and upsample != 2, M, Cout, x.device)
+    w3 = weight_planes(w)
     # algorithmic FLOPs = the reference's nn.Conv2d (3x3 taps, un-split Cin), also for the 4/9-MAC phase form
     _timed(lambda: f"conv3x3_{_dt(x.dtype)}_{_tile_tag(M, Cout, 9 * Cin, x.dtype, ws, f32_residual=residual is not None and out.dtype == torch.float32, conv=True)}",
            2.0 * M * Cout * 9 * (Cin if flops_cin is None else flops_cin),
            lambda: _lib.check(_lib.lib().sdamd_conv3x3(_p(x), _p(w), _p(out), _p(bias), _p(residual), B, H, W, Cin, Cout, stride,
                                                        pad_mode, upsample, int(act), _code(x.dtype), int(out_f32),
-                                                       _p(ws), ws.numel(), _p(stats), wrote, _stream())),
+                                                       _p(ws), ws.numel(), _p(stats), wrote, _p(w3), _stream())),
            lambda: f"M{M} N{Cout} K{9 * Cin} s{stride}{' up' if upsample else ''}{' +res' if residual is not None else ''}{' f32out' if out_f32 else ''}",
            nbytes)
     _stats_attach(out, stats, wrote)

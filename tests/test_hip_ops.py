@@ -681,6 +681,39 @@ def test_f32_attention_modes_against_float64(B, H, d, Sq, Skv, causal):
     assert err["exact"] < 5e-6 and err["bf16x3"] <= 1.25 * err["exact"] + 1e-8, err
 
 
+@pytest.mark.parametrize("impl", [0, 2, 3])
+def test_f32_weight_planes_are_bit_equal_to_in_register_splits(impl, monkeypatch):
+    """sdamd_split3_weights + the planes kernels (gemm2.hip, WPL) form exactly the products of the kernels that split
+    the weight fragments in registers, in the same order: results must be bit-equal (GEMM with residual, conv3x3 with
+    and without stride, the phase-form upsample conv, auto plan / forced LDS-DMA tiles / split-K)."""
+    from sd_amd import _lib
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(3)
+    old = L.sdamd_set_gemm_impl(impl)
+    try:
+        assert ops.get_f32_mode() == "bf16x3"
+        a, w, r = torch.randn(2048, 640, generator=g).to(DEV), (torch.randn(1920, 640, generator=g) / 25).to(DEV), torch.randn(2048, 1920, generator=g).to(DEV)
+        x, cw, cb = torch.randn(2, 32, 32, 320, generator=g).to(DEV), (torch.randn(640, 9 * 320, generator=g) / 50).to(DEV), torch.randn(640, generator=g).to(DEV)
+        uw = (torch.randn(4, 320, 4 * 320, generator=g) / 30).to(DEV)
+        outs = {}
+        for planes in (False, True):
+            monkeypatch.setattr(ops, "USE_WEIGHT_PLANES", planes)
+            outs[planes] = (ops.gemm(a, w, None, r), ops.conv3x3(x, cw, cb, None, 1, 0, False), ops.conv3x3(x, cw, cb, None, 2, 1, False),
+                            ops.conv3x3(x, uw, cb[:320].contiguous(), None, 1, 0, 2))
+        assert ops.weight_planes(w) is not None and ops.weight_planes(w) is ops.weight_planes(w)      # cached per tensor
+        for got, want in zip(outs[True], outs[False]):
+            assert torch.equal(got, want), float((got - want).abs().max())
+        ref = a.double() @ w.double().t() + r.double()
+        assert float((outs[True][0].double() - ref).norm() / ref.norm()) < 2e-6
+        # the planes themselves: hi + mid + lo == w exactly, K-tile layout [hi | mid | lo] x 32
+        pl = ops.weight_planes(w).float().view(1920, 640 // 32, 3, 32).sum(dim=2)
+        k = torch.arange(32)
+        slot = ((k % 16) // 4) * 8 + (k // 16) * 4 + (k % 4)
+        assert torch.equal(pl[:, :, slot.to(DEV)].reshape(1920, 640), w)
+    finally:
+        L.sdamd_set_gemm_impl(old)
+
+
 def test_argument_errors_are_reported():
     from sd_amd import _lib
     a = torch.zeros((4, 100), device=DEV)
