@@ -7,7 +7,7 @@ import pytest
 import torch
 
 import sd_amd
-from sd_amd import attention, clip, decoder, diffusion, encoder, engine, pipeline, synth
+from sd_amd import attention, clip, decoder, diffusion, encoder, engine, ops, pipeline, synth
 from oracle import sd_oracle as O
 from conftest import golden, rel_l2, hin, cpu_state_dicts
 
@@ -171,6 +171,29 @@ def _check_final_image(models, img, final_latents, g, dtype):
         assert diff.max() <= 1 and (diff > 0).mean() < 0.01, (diff.max(), (diff > 0).mean())
     else:
         assert rel_l2(img.astype(np.float32), ref_img.astype(np.float32)) < TOL[dtype]
+
+
+def test_fp32_weight_planes_are_made_once_and_exact_mode_matches(models):
+    """fp32 Diffusion.forward (BASELINE config 2): the bf16x3 weight planes (ops.weight_planes) are made on the first
+    call only -- every GEMM / conv weight the model hands to the kernels is a cached, prepared tensor, never a per-call
+    temporary -- and the exact f32-MFMA mode gives the same output to f32-rounding level (both within the fp32 budget
+    of the reference golden)."""
+    g = golden("diffusion")
+    ctx = torch.from_numpy(golden("clip")["out"]).to(DEV)
+    lat, temb = hin("diff.lat.64", (2, 4, 64, 64), 2.0).to(DEV), pipeline.get_time_embedding(980).to(DEV)
+    dm = with_dtype(models["diffusion"], torch.float32)
+    out = dm(lat, ctx, temb)
+    n = len(ops._W3)
+    assert n > 100                                   # the UNet's Linear / conv weights
+    out2 = dm(lat, ctx, temb)
+    assert len(ops._W3) == n and torch.equal(out, out2)
+    old = ops.set_f32_mode("exact")
+    try:
+        exact = dm(lat, ctx, temb)
+    finally:
+        ops.set_f32_mode(old)
+    assert rel_l2(out.cpu(), g["out64"]) < TOL[torch.float32] and rel_l2(exact.cpu(), g["out64"]) < TOL[torch.float32]
+    assert rel_l2(out.cpu(), exact.cpu()) < 5e-6
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
