@@ -20,6 +20,9 @@ from . import engine, ops
 from .attention import CrossAttention, SelfAttention
 
 _ATTENTION_TYPES = ("xformers", "flashattention", "default")  # all map to the one HIP implementation
+# Classifier-free guidance runs the UNet on [latents; latents] with two prompts: until the first cross attention the two
+# halves are the same tensor.  True: UNET.run(copies=2) computes that shared prefix once (A/B switch for experiments).
+SHARE_CFG_PREFIX = True
 
 
 class UNET_ResidualBlock(engine.HipModule):
@@ -102,6 +105,40 @@ class UNET_AttentionBlock(engine.HipModule):
             return engine.conv1x1_presplit(ts.view(B, H, W, 2 * C), self.conv_output, x, want_stats=True)
         t = engine.linear(g, self.linear_geglu_2, residual=t)
         return engine.conv1x1(t.view(B, H, W, C), self.conv_output, residual=x, compute_dtype=dt, want_stats=True)
+
+    def run_cfg_shared(self, x, kv):
+        """``run`` for a block whose input is the SAME for the two halves of a classifier-free-guidance batch
+        (pipeline.py:147 feeds [latents; latents]; only the prompt differs): x [B,h,w,C], kv [2B,77,2C] -> [2B,h,w,C].
+        Everything up to the cross attention -- GroupNorm, conv_input, LayerNorm, self attention, the cross attention's
+        LayerNorm and Q projection -- depends on x alone and is computed once; the two halves split where the prompt
+        enters (one cross-attention launch per half on the shared Q) and the residual adds that still read shared
+        tensors run per half into the halves of the 2B result.  Same arithmetic per element as ``run`` on the
+        duplicated batch."""
+        B, H, W, C = x.shape
+        dt, td = self.compute_dtype, x.dtype
+        a2 = self.attention_2
+        t = engine.conv1x1(engine.groupnorm(x, self.groupnorm, silu=False, out_dtype=dt), self.conv_input,
+                           out_dtype=td).view(B, H * W, C)
+        t = engine.self_attention(engine.layernorm(t, self.layernorm_1, dt), self.attention_1, residual=t)
+        q = engine.linear(engine.layernorm(t, self.layernorm_2, dt), a2.q_proj)
+        o = torch.empty((2 * B, H * W, C), dtype=q.dtype, device=q.device)
+        t2 = torch.empty((2 * B, H * W, C), dtype=td, device=q.device)
+        for half in range(2):
+            kvh = kv[half * B:(half + 1) * B]
+            ops.attention(q, kvh[..., :C], kvh[..., C:], a2.n_heads, False, out=o[half * B:(half + 1) * B])
+            engine.linear(o[half * B:(half + 1) * B], a2.out_proj, t, out=t2[half * B:(half + 1) * B])
+        g = engine.linear_geglu(engine.layernorm(t2, self.layernorm_3, dt), self.linear_geglu_1)
+        ts = engine.linear_hilo(g, self.linear_geglu_2, t2) if dt == torch.bfloat16 else None
+        out = torch.empty((2 * B, H, W, C), dtype=td, device=q.device)
+        if ts is None:
+            t2 = engine.linear(g, self.linear_geglu_2, residual=t2)
+        for half in range(2):
+            sl = slice(half * B, (half + 1) * B)
+            if ts is not None:
+                engine.conv1x1_presplit(ts[sl].view(B, H, W, 2 * C), self.conv_output, x, out=out[sl])
+            else:
+                engine.conv1x1(t2[sl].view(B, H, W, C), self.conv_output, residual=x, compute_dtype=dt, out=out[sl])
+        return out
 
     def forward(self, x, prompt):
         kv = self.prompt_kv(prompt.contiguous())
@@ -238,6 +275,11 @@ class UNET(engine.HipModule):
             if i == 0:
                 c = stage[0]
                 x = ops.conv3x3_cin_small(x_nchw, engine.conv3x3_cin_small_w(c), engine.f32(c.bias), dt, copies)
+            elif i == 1 and copies == 2 and SHARE_CFG_PREFIX:
+                # both halves of the batch are still the same tensor here: the first residual block and the first
+                # attention block up to its cross attention run once, on one half (UNET_AttentionBlock.run_cfg_shared)
+                res, att = stage[0], stage[1]
+                x = att.run_cfg_shared(res.run(x[:x.shape[0] // 2], tbias[id(res)]), kv[id(att)])
             else:
                 x = self._stage(stage, x, kv, tbias)
             skips.append(x)

@@ -113,8 +113,8 @@ def _out_f32(x, residual, out_dtype):
     return out_dtype == torch.float32 and x.dtype != torch.float32
 
 
-def linear(x, lin, residual=None, act=ops.ACT_NONE, out_dtype=None):
-    return ops.gemm(x, linear_w(lin, x.dtype), bias_of(lin), residual, act, _out_f32(x, residual, out_dtype))
+def linear(x, lin, residual=None, act=ops.ACT_NONE, out_dtype=None, out=None):
+    return ops.gemm(x, linear_w(lin, x.dtype), bias_of(lin), residual, act, _out_f32(x, residual, out_dtype), out=out)
 
 
 def linear_geglu(x, lin):
@@ -138,14 +138,14 @@ def linear_hilo(x, lin, residual):
     return ops.gemm(x, linear_w(lin, x.dtype), bias_of(lin), residual, ops.ACT_NONE, out_hilo=True)
 
 
-def conv1x1_presplit(xs, conv, residual, want_stats=False):
+def conv1x1_presplit(xs, conv, residual, want_stats=False, out=None):
     """conv1x1 of an operand that already is the hi|lo pair [..., 2C] (see conv1x1): f32 residual, f32 result."""
     w2 = packed(conv.weight, "c1x2", torch.bfloat16,
                 lambda w: w.reshape(w.shape[0], w.shape[1]).to(torch.bfloat16).repeat(1, 2).contiguous())
-    return ops.gemm(xs, w2, bias_of(conv), residual, ops.ACT_NONE, True, flops_k=conv.in_channels, want_stats=want_stats)
+    return ops.gemm(xs, w2, bias_of(conv), residual, ops.ACT_NONE, True, flops_k=conv.in_channels, want_stats=want_stats, out=out)
 
 
-def conv1x1(x, conv, residual=None, out_dtype=None, compute_dtype=None, x2=None, want_stats=False):
+def conv1x1(x, conv, residual=None, out_dtype=None, compute_dtype=None, x2=None, want_stats=False, out=None):
     """x NHWC [B,H,W,C].  An f32 ``x`` under a bf16 compute dtype is the residual trunk itself:
     it goes through the MFMA as two bf16 terms (hi|lo) against [W|W] instead of being rounded.
     ``x2`` (that mode only): the operand is the channel concat [x | x2]."""
@@ -154,10 +154,10 @@ def conv1x1(x, conv, residual=None, out_dtype=None, compute_dtype=None, x2=None,
                     lambda w: w.reshape(w.shape[0], w.shape[1]).to(torch.bfloat16).repeat(1, 2).contiguous())
         xs = ops.split_hilo(x, x2)
         return ops.gemm(xs, w2, bias_of(conv), residual, ops.ACT_NONE, _out_f32(xs, residual, out_dtype), flops_k=conv.in_channels,
-                        want_stats=want_stats)
+                        want_stats=want_stats, out=out)
     assert x2 is None
     return ops.gemm(x, conv1x1_w(conv, x.dtype), bias_of(conv), residual, ops.ACT_NONE, _out_f32(x, residual, out_dtype),
-                    want_stats=want_stats)
+                    want_stats=want_stats, out=out)
 
 
 def conv3x3(x, conv, residual=None, stride=1, pad_mode=0, upsample=False, bias=None, out_dtype=None, want_stats=False):

@@ -437,7 +437,7 @@ def gemm_hilo_fused(M, N, K, dtype):
     return tile in (64160, 128160, 128320, 256256, 256320)      # the LDS-DMA tiles (gemm2.hip); the register-staged ones have no such epilogue
 
 
-def gemm(a, w, bias=None, residual=None, act=ACT_NONE, out_f32=False, out_hilo=False, flops_k=None, want_stats=False):
+def gemm(a, w, bias=None, residual=None, act=ACT_NONE, out_f32=False, out_hilo=False, flops_k=None, want_stats=False, out=None):
     """a [..., K] (last dim contiguous, uniform row stride), w [N, K] -> [..., N].  The result (and the
     residual, which must have the result's dtype) is f32 when ``out_f32``, else a's dtype.
     ``out_hilo``: f32 residual, result bf16 [..., 2N] = [bf16(v) | bf16(v - bf16(v))] (see split_hilo).
@@ -465,7 +465,10 @@ def gemm(a, w, bias=None, residual=None, act=ACT_NONE, out_f32=False, out_hilo=F
     if out_hilo:
         assert a.dtype == torch.bfloat16 and act == ACT_NONE and not out_f32
         res_dtype, n_out, out_f32 = torch.float32, 2 * N, 2
-    out = torch.empty(lead + (n_out,), dtype=out_dtype, device=a.device)
+    if out is None:
+        out = torch.empty(lead + (n_out,), dtype=out_dtype, device=a.device)
+    else:   # caller's buffer (e.g. one half of a batch): same shape, dtype, dense
+        assert out.dtype == out_dtype and out.is_contiguous() and out.numel() == M * n_out and out.shape[-1] == n_out and out.device == a.device
     ldr = 0
     if residual is not None:
         assert residual.dtype == res_dtype and residual.is_contiguous() and residual.numel() == M * (N if out_hilo else n_out), \
@@ -632,7 +635,7 @@ def conv3x3_cout_small(x, w_packed, bias, cout):
     return out
 
 
-def attention(q, k, v, n_heads, causal=False):
+def attention(q, k, v, n_heads, causal=False, out=None):
     """q [B,Sq,C] and k, v [B,Skv,C] views (last dim contiguous; may be column slices of a fused
     projection) -> [B,Sq,C].  Head h = columns [h*d, (h+1)*d), d = C / n_heads."""
     _dev(q, k, v)
@@ -641,7 +644,10 @@ def attention(q, k, v, n_heads, causal=False):
     d = C // n_heads
     assert k.shape == (B, Skv, C) and v.shape == (B, Skv, C) and q.dtype == k.dtype == v.dtype
     assert q.stride(2) == 1 and k.stride(2) == 1 and v.stride(2) == 1
-    out = torch.empty((B, Sq, C), dtype=q.dtype, device=q.device)
+    if out is None:
+        out = torch.empty((B, Sq, C), dtype=q.dtype, device=q.device)
+    else:
+        assert out.shape == (B, Sq, C) and out.dtype == q.dtype and out.stride(2) == 1 and out.device == q.device
     _timed(f"attention_{_dt(q.dtype)}_d{d}", 4.0 * B * n_heads * Sq * Skv * d,
            lambda: _lib.check(_lib.lib().sdamd_attention(_p(q), _p(k), _p(v), _p(out), B, n_heads, Sq, Skv, d,
                                                          q.stride(0), q.stride(1), k.stride(0), k.stride(1), v.stride(0),

@@ -197,6 +197,27 @@ def test_fp32_weight_planes_are_made_once_and_exact_mode_matches(models):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+def test_cfg_shared_prefix_equals_the_duplicated_batch(models, dtype, monkeypatch):
+    """UNET.run(copies=2) (the classifier-free-guidance batch [latents; latents], pipeline.py:147) computes the first
+    residual block and the first attention block up to its cross attention once (diffusion.SHARE_CFG_PREFIX): same
+    result as running the duplicated batch, to rounding (fp32: summation order of different tile plans only)."""
+    dm = with_dtype(models["diffusion"], dtype)
+    ctx = torch.from_numpy(golden("clip")["out"]).to(DEV)                      # [2, 77, 768]: two different prompts
+    lat = hin("diff.lat.64", (2, 4, 64, 64), 2.0)[:1].to(DEV).contiguous()
+    kv = dm.unet.prompt_state(ctx)
+    tb = dm.unet.time_bias_slices(dm.unet.time_bias_table(dm.time_embedding(pipeline.get_time_embedding(500).to(DEV))).reshape(-1))
+    outs = {}
+    for share in (False, True):
+        monkeypatch.setattr(diffusion, "SHARE_CFG_PREFIX", share)
+        outs[share] = dm.run(lat, kv, tb, copies=2)
+    assert tuple(outs[True].shape) == (2, 4, 64, 64)
+    full = dm(torch.cat([lat, lat]), ctx, pipeline.get_time_embedding(500).to(DEV))   # the reference-signature forward: no sharing
+    assert rel_l2(outs[False].cpu(), full.cpu()) < (1e-6 if dtype == torch.float32 else 1e-3)
+    assert rel_l2(outs[True].cpu(), outs[False].cpu()) < (1e-5 if dtype == torch.float32 else 6e-3)
+    assert not torch.equal(outs[True][0], outs[True][1])                       # the two prompts do differ
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_generate_txt2img_3step_vs_reference(models, dtype):
     g = golden("pipeline_txt2img_3step")
     img, lat, final = _gen(models, dtype, steps=3)
