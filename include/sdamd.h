@@ -180,7 +180,7 @@ int sdamd_set_gemm_impl(int impl);
  * argument only queries.  No reference counterpart: torch's fp32 nn.Linear / nn.Conv2d (diffusion.py, decoder.py) is
  * the function both modes compute.
  *   1 (default) "bf16x3": every f32 operand value is split exactly into three bf16 terms in registers and a product is
- *      accumulated in f32 from the six partial products >= 2^-16 of it on v_mfma_f32_16x16x32_bf16; the dropped terms
+ *      accumulated in f32 from the six partial products >= 2^-16 of it on v_mfma_f32_16x16x32_bf16 (GEMM, conv3x3, attention with d <= 160); the dropped terms
  *      are below one f32 rounding of the product.  Measured against float64 the result is as close as mode 0's
  *      (tests/test_hip_ops.py::test_f32_modes_against_float64), at 1.3-1.5x its speed.  inf inputs give NaN.
  *   0 "exact": v_mfma_f32_16x16x4_f32, bitwise an fmaf chain over k. */

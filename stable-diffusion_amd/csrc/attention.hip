@@ -914,10 +914,11 @@ extern "C" int sdamd_attention(const void* q, const void* k, const void* v, void
   if (d == 512) return dtype == SDAMD_BF16 ? launch_attn512<bf16_t>(a, B, st) : launch_attn512<float>(a, B, st);
   if (d == 40 && dtype == SDAMD_BF16 && a.debug == 17) return launch_attn<bf16_t, 40, true>(a, B, st);
   { extern int g_f32_emu;
-    if (dtype == SDAMD_F32 && g_f32_emu) {   // sdamd_set_f32_mode: f32 attention on the bf16 matrix pipe (d = 160 keeps the f32 MFMA: registers)
+    if (dtype == SDAMD_F32 && g_f32_emu) {   // sdamd_set_f32_mode: f32 attention on the bf16 matrix pipe (the 512-wide VAE head keeps the f32 MFMA)
       if (d == 40) return launch_attn_f32x3<40>(a, B, st);
       if (d == 64) return launch_attn_f32x3<64>(a, B, st);
       if (d == 80) return launch_attn_f32x3<80>(a, B, st);
+      if (d == 160) return launch_attn_f32x3<160>(a, B, st);   // (256 VGPRs + 89 AGPRs, one wave per SIMD: its grids are small anyway)
     } }
 #define ATT(TT) switch (d) { case 40: return launch_attn<TT, 40>(a, B, st); case 64: return launch_attn<TT, 64>(a, B, st); \
                              case 80: return launch_attn<TT, 80>(a, B, st); default: return launch_attn<TT, 160>(a, B, st); }

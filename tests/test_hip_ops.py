@@ -662,8 +662,7 @@ def test_f32_modes_against_float64(impl):
                                                   (2, 12, 64, 77, 77, True), (1, 8, 160, 256, 256, False)])
 def test_f32_attention_modes_against_float64(B, H, d, Sq, Skv, causal):
     """attention.py:46-68 in fp32: the default kernel (attn_f32x3_kernel: Q, K, V and P split into three bf16 terms, six
-    MFMA products each) and the exact f32-MFMA kernel against float64 softmax(QK^T/sqrt(d))V, scores spread over +-12.
-    d = 160 has no bf16x3 kernel (both modes run the exact one)."""
+    MFMA products each) and the exact f32-MFMA kernel against float64 softmax(QK^T/sqrt(d))V, scores spread over +-12."""
     g = torch.Generator().manual_seed(11)
     C = H * d
     qq, kk, vv = torch.randn(B, Sq, C, generator=g) * 3.0, torch.randn(B, Skv, C, generator=g), torch.randn(B, Skv, C, generator=g)
