@@ -120,8 +120,8 @@ def build_models(device, dtype, keep_cpu):
 class Txt2ImgJob:
     """Everything of generate() that can be prepared ahead, for a fixed batch of prompts/seeds."""
 
-    def __init__(self, models, first_image, batch, denoise_steps, cfg_scale, device, use_graph=True):
-        self.models, self.B = models, batch
+    def __init__(self, models, first_image, batch, denoise_steps, cfg_scale, device, use_graph=True, gather=True):
+        self.models, self.B, self.gather = models, batch, gather
         ids = [synth.synthetic_token_ids(first_image + i) for i in range(batch)]
         self.pos = torch.tensor(ids, dtype=torch.long, device=device)
         self.neg = torch.tensor([synth.EMPTY_PROMPT_IDS] * batch, dtype=torch.long, device=device)
@@ -137,7 +137,7 @@ class Txt2ImgJob:
         self.loop.reset(self.latents0)
         final = self.loop.run()
         images = pipeline.decode_to_uint8(self.models["decoder"], final)
-        return distributed.all_gather_images(images)
+        return distributed.all_gather_images(images) if self.gather else images   # (rank-local legs must not enter a collective)
 
 def unet_step_ms(loop, latents0, iters=20, warm=3):
     """one captured Diffusion forward + CFG + step; median of >= 20 after 3 warm-ups, HIP events."""
@@ -158,7 +158,7 @@ def unet_step_ms(loop, latents0, iters=20, warm=3):
 
 def roofline_leg(models, args, device):
     """One eager pass of the same step with HIP-event pairs around every heavy launch."""
-    job = Txt2ImgJob(models, 0, args.batch, args.denoise_steps, 7.5, device, use_graph=False)
+    job = Txt2ImgJob(models, 0, args.batch, args.denoise_steps, 7.5, device, use_graph=False, gather=False)   # rank 0 only: no collective
     job.step()                                     # warm (weights already packed)
     torch.cuda.synchronize()
     ops.PROFILER = ops.LaunchTimer()

@@ -126,3 +126,14 @@ def test_bench_labels_map_to_kernel_symbols():
     assert ks("groupnorm_f32") == "groupnorm_f32"
     traffic, source = bench.pmc_traffic("gemm2_kernel<unsigned short, 128, 160, 2, 2, 2, true, 0>")
     assert (traffic is None and source is None) or (traffic > 1e8 and source.endswith("_pmc_traffic.json"))        # profiles/r01_pmc_traffic.json carries the dominant kernel under this name
+
+
+def test_bench_rank_local_legs_do_not_enter_collectives():
+    """bench.py with N > 1: after the timed region every rank but 0 returns; the legs rank 0 then runs alone (roofline,
+    latency) must not call the all-gather (a 2-rank rehearsal crashed exactly there before `gather=False` existed)."""
+    import inspect
+    import bench
+    assert "gather=False" in inspect.getsource(bench.roofline_leg)
+    src = inspect.getsource(bench.Txt2ImgJob.step)
+    assert "if self.gather else images" in src
+
