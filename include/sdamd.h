@@ -183,7 +183,9 @@ int sdamd_set_gemm_impl(int impl);
  *      accumulated in f32 from the six partial products >= 2^-16 of it on v_mfma_f32_16x16x32_bf16 (GEMM, conv3x3, attention with d <= 160); the dropped terms
  *      are below one f32 rounding of the product.  Measured against float64 the result is as close as mode 0's
  *      (tests/test_hip_ops.py::test_f32_modes_against_float64), at 1.3-1.5x its speed.  inf inputs give NaN.
- *   0 "exact": v_mfma_f32_16x16x4_f32, bitwise an fmaf chain over k. */
+ *   0 "exact": v_mfma_f32_16x16x4_f32, bitwise an fmaf chain over k.
+ * Process-wide and read at launch time: set it before launching from several host threads, not while they launch
+ * (like sdamd_set_gemm_impl it is an unsynchronised global). */
 int sdamd_set_f32_mode(int mode);
 /* ---- implicit-GEMM conv3x3 over NHWC: nn.Conv2d(k=3) of diffusion.py:9,13,146,204-221,
  * decoder.py:10-13,92-111, encoder.py:13-45.  w [Cout][ky][kx][Cin]; pad_mode 0 = pad 1,
