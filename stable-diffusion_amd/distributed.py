@@ -44,29 +44,33 @@ def shard_range(total, rank, world):
 
 
 def all_gather_images(images, total=None):
-    """images uint8 [b_local, H, W, 3] on every rank -> [total, H, W, 3] in rank order.
-    Equal shard sizes use one all_gather_into_tensor; ragged shards are padded to the largest."""
+    """images uint8 [b_local, H, W, 3] on every rank -> [total, H, W, 3] in rank order, with exactly ONE collective
+    (SURVEY.md §8e): every rank knows every shard's size from ``shard_range(total, r, world)`` -- no size exchange.
+    ``total`` = images over all ranks (default: every rank holds ``images.shape[0]``).  Ragged shards (sizes differ
+    by at most 1) are padded to the largest inside the same single ``all_gather_into_tensor``."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
+        if total is not None and images.shape[0] != total:
+            raise RuntimeError(f"gathered {images.shape[0]} images, expected {total}")
         return images
-    world = dist.get_world_size()
+    world, rank = dist.get_world_size(), dist.get_rank()
     images = images.contiguous()
     if images.is_cuda and dist.get_backend() == "gloo":      # rehearsal only (see init_from_env): gather through the host
         return all_gather_images(images.cpu(), total).to(images.device)
-    sizes = [torch.zeros(1, dtype=torch.int64, device=images.device) for _ in range(world)]
-    dist.all_gather(sizes, torch.tensor([images.shape[0]], dtype=torch.int64, device=images.device))
-    sizes = [int(s) for s in sizes]
-    if len(set(sizes)) == 1:
-        out = torch.empty((world * sizes[0],) + tuple(images.shape[1:]), dtype=images.dtype, device=images.device)
-        dist.all_gather_into_tensor(out, images)
-    else:
-        mx = max(sizes)
-        pad = torch.zeros((mx,) + tuple(images.shape[1:]), dtype=images.dtype, device=images.device)
-        pad[:images.shape[0]] = images
-        bufs = [torch.empty_like(pad) for _ in range(world)]
-        dist.all_gather(bufs, pad)
-        out = torch.cat([b[:n] for b, n in zip(bufs, sizes)])
-    if total is not None and out.shape[0] != total:
-        raise RuntimeError(f"gathered {out.shape[0]} images, expected {total}")
+    if total is None:
+        total = world * images.shape[0]
+    sizes = [hi - lo for lo, hi in (shard_range(total, r, world) for r in range(world))]
+    if images.shape[0] != sizes[rank]:
+        raise RuntimeError(f"rank {rank} holds {images.shape[0]} images, shard_range({total}, {rank}, {world}) says {sizes[rank]}")
+    mx = max(sizes)
+    tail = tuple(images.shape[1:])
+    send = images
+    if sizes[rank] != mx:
+        send = torch.zeros((mx,) + tail, dtype=images.dtype, device=images.device)
+        send[:sizes[rank]] = images
+    out = torch.empty((world * mx,) + tail, dtype=images.dtype, device=images.device)
+    dist.all_gather_into_tensor(out, send)
+    if min(sizes) != mx:
+        out = torch.cat([out[r * mx:r * mx + n] for r, n in enumerate(sizes)])
     return out
 
 

@@ -42,13 +42,27 @@ def _worker(rank, world, port, total, q):
     lo, hi = d.shard_range(total, rank, world)
     # "decode" of image i = a constant image with value i: per-image work independent of the shard
     imgs = torch.stack([torch.full((4, 4, 3), i, dtype=torch.uint8) for i in range(lo, hi)])
+    # count every collective torch.distributed issues during the gather: SURVEY.md §8e says exactly one
+    import torch.distributed as dist
+    calls = []
+    for name in ("all_gather", "all_gather_into_tensor", "all_reduce", "broadcast", "all_to_all", "gather", "all_gather_object"):
+        orig = getattr(dist, name)
+        setattr(dist, name, (lambda o, n: lambda *a, **k: (calls.append(n), o(*a, **k))[1])(orig, name))
     out = d.all_gather_images(imgs, total)
+    assert calls == ["all_gather_into_tensor"], calls
     worst = d.max_over_ranks(float(rank + 1), torch.device("cpu"))
     d.barrier()
     q.put((rank, out.numpy(), worst))
 
 
-@pytest.mark.parametrize("total", [8, 5])
+def test_config4_shard_sizes():
+    """BASELINE config 4: global batch 64 strong-scaled over 1/2/4/8 GPUs = 64/N images per rank."""
+    for world in (1, 2, 4, 8):
+        sizes = [hi - lo for lo, hi in (distributed.shard_range(64, r, world) for r in range(world))]
+        assert sizes == [64 // world] * world
+
+
+@pytest.mark.parametrize("total", [8, 5, 64])
 def test_all_gather_returns_rank_ordered_images(total):
     world, port = 2, _free_port()
     ctx = mp.get_context("spawn")
