@@ -39,7 +39,7 @@ int sdamd_device_count(void); /* >=0, or -hipError when no driver/GPU */
  * latents [B][n] f32 in/out; eps [2B][n] f32 = UNet output, [pos_0..pos_B-1, neg_0..neg_B-1]
  * (do_cfg=0: eps [B][n]); noise [steps][B][n] pre-drawn host noise (may be null when no row
  * has has_noise); coef [steps][8] = {sqrt(abar_t), sqrt(1-abar_t), c0, cx, sigma, has_noise,
- * cx_on_eps, 0} computed on the host in the reference's op order:
+ * cx_on_eps, cfg} computed on the host in the reference's op order:
  *   x0 = (x - sqrt(1-abar_t)*e) / sqrt(abar_t);  x' = x0*c0 + cx*(cx_on_eps ? e : x) [+ sigma*noise]
  * cx_on_eps = 0 is the DDPM step (ddpm.py:59-85), 1 the deterministic DDIM step
  * (sampler/ddim.py:50-72: c0 = sqrt(abar_prev), cx = sqrt(1-abar_prev), no noise).
@@ -47,7 +47,9 @@ int sdamd_device_count(void); /* >=0, or -hipError when no driver/GPU */
  * null; coef (and noise) have n_steps rows: a host `step` outside [0, n_steps) is an error, a
  * device index outside it makes the launch a no-op (latents untouched) instead of reading past
  * the tables.  A null `noise` is read as "no noise" whatever has_noise says: the caller checks its
- * table (pipeline.DenoiseLoop does).  Bit-exact vs torch CPU. */
+ * table (pipeline.DenoiseLoop does).  A NaN `cfg_scale` means "read the guidance scale from column 7
+ * of this step's coef row": a captured hipGraph then follows a new scale written into the table.
+ * Bit-exact vs torch CPU. */
 int sdamd_cfg_ddpm_step(float* latents, const float* eps, const float* noise, const float* coef,
                         const int* step_ptr, int step, int n_steps, float cfg_scale, int do_cfg,
                         int B, int n, void* stream);
@@ -98,9 +100,6 @@ int sdamd_groupnorm_nhwc_pre(const void* x1, const void* x2, int C1, int C2, voi
 /* nn.LayerNorm(C): diffusion.py:109,117,126; clip.py:54,63,95; dtypes as for groupnorm */
 int sdamd_layernorm(const void* x, void* y, const float* gamma, const float* beta, int rows, int C,
                     float eps, int dtype, int out_dtype, void* stream);
-/* softmax(scores*scale) per row, f32 in, dtype out (unfused d_head=512 VAE attention) */
-int sdamd_softmax_rows(const float* scores, void* probs, int rows, int n, float scale, int dtype,
-                       void* stream);
 
 /* ---- elementwise */
 /* diffusion.py:128-130: in [rows][2F] (value|gate) -> out [rows][F] = value*gelu_erf(gate) */
@@ -126,8 +125,6 @@ int sdamd_split_hilo_cat(const float* src1, const float* src2, void* dst, long l
                          int K2, void* stream);
 /* F.silu on an f32 vector (diffusion.py:32) */
 int sdamd_silu(const float* src, float* dst, long long n, void* stream);
-int sdamd_transpose(const void* src, void* dst, int batch, int rows, int cols, int ld_src,
-                    long long stride_src, long long stride_dst, int dtype, void* stream);
 /* pipeline.py:158-160: rescale (-1,1)->(0,255), clamp, truncating cast; NCHW f32 -> NHWC u8 */
 int sdamd_image_to_uint8(const float* src, unsigned char* dst, int B, int HW, void* stream);
 /* pipeline.py:99-104: uint8 HWC -> NCHW f32 in (-1,1) */

@@ -28,7 +28,6 @@ SIGNATURES = {
     "sdamd_groupnorm_nhwc_pre": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _i, _i, _i, _vp]),
     "sdamd_groupnorm_nhwc_cat": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _f, _i, _i, _i, _vp]),
     "sdamd_layernorm": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _i, _i, _vp]),
-    "sdamd_softmax_rows": (_i, [_vp, _vp, _i, _i, _f, _i, _vp]),
     "sdamd_geglu": (_i, [_vp, _vp, _ll, _i, _i, _vp]),
     "sdamd_clip_embed": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "sdamd_concat_nhwc": (_i, [_vp, _vp, _vp, _ll, _i, _i, _i, _vp]),
@@ -39,7 +38,6 @@ SIGNATURES = {
     "sdamd_split_hilo": (_i, [_vp, _vp, _ll, _i, _vp]),
     "sdamd_split_hilo_cat": (_i, [_vp, _vp, _vp, _ll, _i, _i, _vp]),
     "sdamd_silu": (_i, [_vp, _vp, _ll, _vp]),
-    "sdamd_transpose": (_i, [_vp, _vp, _i, _i, _i, _i, _ll, _ll, _i, _vp]),
     "sdamd_image_to_uint8": (_i, [_vp, _vp, _i, _i, _vp]),
     "sdamd_uint8_to_image": (_i, [_vp, _vp, _i, _i, _vp]),
     "sdamd_vae_post_quant": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),

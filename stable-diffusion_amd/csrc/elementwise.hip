@@ -24,6 +24,7 @@ __global__ __launch_bounds__(256) void cfg_ddpm_step_kernel(float* __restrict__ 
   const float* c = coef + (size_t)s * 8;
   const float sa = c[0], sb = c[1], c0 = c[2], cx = c[3], sigma = c[4];
   const bool has_noise = c[5] != 0.0f && noise != nullptr, cx_on_eps = c[6] != 0.0f;
+  if (cfg_scale != cfg_scale) cfg_scale = c[7];   // NaN argument: the guidance scale rides in the table (a captured graph can then change it)
   const size_t total = (size_t)B * n;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
     float e;

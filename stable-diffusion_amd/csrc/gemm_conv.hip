@@ -357,24 +357,6 @@ __global__ __launch_bounds__(256) void conv3x3_cout_small_kernel(const T* __rest
   }
 }
 
-// batched 2-D transpose of T: src [batch][rows][ld_src] (first `cols` columns) -> dst [batch][cols][rows]
-template <typename T>
-__global__ __launch_bounds__(256) void transpose_kernel(const T* __restrict__ src, T* __restrict__ dst, int rows, int cols,
-                                                        int ld_src, long long s_src, long long s_dst) {
-  __shared__ T tile[32][33];
-  const int b = blockIdx.z, r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-  for (int i = ty; i < 32; i += 8) {
-    int r = r0 + i, c = c0 + tx;
-    if (r < rows && c < cols) tile[i][tx] = src[(size_t)b * s_src + (size_t)r * ld_src + c];
-  }
-  __syncthreads();
-  for (int i = ty; i < 32; i += 8) {
-    int c = c0 + i, r = r0 + tx;
-    if (r < rows && c < cols) dst[(size_t)b * s_dst + (size_t)c * rows + r] = tile[tx][i];
-  }
-}
-
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
@@ -643,18 +625,5 @@ extern "C" int sdamd_conv3x3_cout_small(const void* x_nhwc, const void* w_packed
   else { if (Cout == 3) CS(float, 3); else if (Cout == 4) CS(float, 4); else CS(float, 8); }
 #undef CS
   SD_LAUNCH_CHECK("conv3x3_cout_small");
-  return 0;
-}
-
-extern "C" int sdamd_transpose(const void* src, void* dst, int batch, int rows, int cols, int ld_src, long long stride_src,
-                               long long stride_dst, int dtype, void* stream) {
-  SD_CHECK(batch > 0 && rows > 0 && cols > 0 && ld_src >= cols, "transpose: bad shape");
-  dim3 grid((cols + 31) / 32, (rows + 31) / 32, batch);
-  hipStream_t st = (hipStream_t)stream;
-  if (dtype == SDAMD_BF16)
-    transpose_kernel<bf16_t><<<grid, 256, 0, st>>>((const bf16_t*)src, (bf16_t*)dst, rows, cols, ld_src, stride_src, stride_dst);
-  else
-    transpose_kernel<float><<<grid, 256, 0, st>>>((const float*)src, (float*)dst, rows, cols, ld_src, stride_src, stride_dst);
-  SD_LAUNCH_CHECK("transpose");
   return 0;
 }

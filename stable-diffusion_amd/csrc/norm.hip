@@ -260,34 +260,6 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x,
 }
 
 // ---------------------------------------------------------------------------------------------
-// Row softmax with scale (for the unfused d_head=512 VAE attention): one block per row,
-// in: f32 scores [rows][n], out: T probabilities [rows][n].
-// ---------------------------------------------------------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ s, T* __restrict__ p, int n,
-                                                           float scale) {
-  __shared__ float red[4];
-  const float* sr = s + (size_t)blockIdx.x * n;
-  T* pr = p + (size_t)blockIdx.x * n;
-  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-  float m = -3.0e38f;
-  for (int i = t; i < n; i += 256) m = fmaxf(m, sr[i]);
-  m = wave_max(m);
-  if (lane == 0) red[w] = m;
-  __syncthreads();
-  m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-  __syncthreads();
-  float sum = 0.f;
-  for (int i = t; i < n; i += 256) sum += expf((sr[i] - m) * scale);
-  sum = wave_sum(sum);
-  if (lane == 0) red[w] = sum;
-  __syncthreads();
-  sum = (red[0] + red[1]) + (red[2] + red[3]);
-  const float inv = 1.0f / sum;
-  for (int i = t; i < n; i += 256) Cvt<T>::st(pr + i, expf((sr[i] - m) * scale) * inv);
-}
-
-// ---------------------------------------------------------------------------------------------
 // host entry points
 // ---------------------------------------------------------------------------------------------
 static int gn_geometry(int C, int V, int* tpp, int* nchunk) {
@@ -595,13 +567,3 @@ extern "C" int sdamd_layernorm(const void* x, void* y, const float* gamma, const
   return 0;
 }
 
-extern "C" int sdamd_softmax_rows(const float* scores, void* probs, int rows, int n, float scale, int dtype, void* stream) {
-  SD_CHECK(rows > 0 && n > 0, "softmax_rows: empty input");
-  hipStream_t st = (hipStream_t)stream;
-  if (dtype == SDAMD_BF16)
-    softmax_rows_kernel<bf16_t><<<rows, 256, 0, st>>>(scores, (bf16_t*)probs, n, scale);
-  else
-    softmax_rows_kernel<float><<<rows, 256, 0, st>>>(scores, (float*)probs, n, scale);
-  SD_LAUNCH_CHECK("softmax_rows");
-  return 0;
-}

@@ -2,7 +2,7 @@
 
 nn.Sequential child indices ("0." ... "25.") are the weights ABI.  Execution is NHWC: the three
 nn.Upsample stages are folded into the following conv's gather, GN+SiLU is one fused pass, the
-512-wide single-head attention runs as MFMA GEMMs around a row softmax, and the last conv writes
+512-wide single-head attention is a flash kernel of its own (attn512_kernel: no [S, S] tensor), and the last conv writes
 the caller's NCHW f32 image directly.  Unlike the reference (decoder.py:128) the caller's latent
 tensor is NOT modified in place.
 """

@@ -7,7 +7,6 @@ launches are capturable into a hipGraph) and never falls back to torch eager mat
 Activation layout is NHWC / token-major: [B, H, W, C] or [B, S, C], float32 or bfloat16.
 """
 import ctypes
-import math
 
 import torch
 
@@ -150,7 +149,8 @@ def ensure_workspaces(device, batch=1):
 
 # ------------------------------------------------------------------ sampler
 def cfg_ddpm_step(latents, eps, noise, coef, step, cfg_scale, do_cfg=True, step_ptr=None, deterministic=False):
-    """In-place on ``latents`` [B,4,h,w] f32; eps [2B,4,h,w] f32 ([pos..., neg...]).  ``noise`` may only be None
+    """In-place on ``latents`` [B,4,h,w] f32; eps [2B,4,h,w] f32 ([pos..., neg...]).  ``cfg_scale=None``: the kernel
+    reads the guidance scale from column 7 of the step's coefficient row.  ``noise`` may only be None
     for a schedule the caller has checked to be noise-free (``deterministic=True``: every coef[:, 5] == 0); the
     kernel reads a null noise pointer as "no noise".  A device-side index (``step_ptr``) outside the schedule makes
     the launch a no-op."""
@@ -173,7 +173,8 @@ def cfg_ddpm_step(latents, eps, noise, coef, step, cfg_scale, do_cfg=True, step_
     # algorithmic bytes: 5 x 4*h*w x 4 B per image-step (eps pos/neg, noise, latents in + out)
     _timed("cfg_ddpm_step", 5.0 * B * n * 4,
            lambda: _lib.check(_lib.lib().sdamd_cfg_ddpm_step(_p(latents), _p(eps), _p(noise), _p(coef), _p(step_ptr), int(step),
-                                                             coef.shape[0], float(cfg_scale), int(do_cfg), B, n, _stream())),
+                                                             coef.shape[0], float("nan") if cfg_scale is None else float(cfg_scale),
+                                                             int(do_cfg), B, n, _stream())),
            f"B{B} n{n}")
     return latents
 
@@ -224,8 +225,8 @@ def groupnorm(x, gamma, beta, eps, silu, out_dtype=None, x2=None):
     ws = _groupnorm_ws(B, x.device)
     L = _lib.lib()
     # statistics left behind by the producing GEMM / conv epilogue (gemm / conv3x3 want_stats): no pass over x for them
-    st1 = getattr(x, "_sd_colstats", None)
-    st2 = None if x2 is None else getattr(x2, "_sd_colstats", None)
+    st1 = _stats_of(x)
+    st2 = None if x2 is None else _stats_of(x2)
     pre = USE_PRODUCER_STATS and st1 is not None and (x2 is None or st2 is not None) and HW % 64 == 0
     if pre:
         assert st1.shape == (B * HW // 64, C1, 2) and (st2 is None or st2.shape == (B * HW // 64, C2, 2))
@@ -261,16 +262,6 @@ def layernorm(x, gamma, beta, eps=1e-5, out_dtype=None):
                                                          _code(x.dtype), _code(out_dtype), _stream())),
            f"rows{x.numel() // C} C{C}")
     return y
-
-
-def softmax_rows(scores, scale, out_dtype):
-    _dev(scores)
-    assert scores.dtype == torch.float32 and scores.is_contiguous()
-    n = scores.shape[-1]
-    out = torch.empty(scores.shape, dtype=out_dtype, device=scores.device)
-    _lib.check(_lib.lib().sdamd_softmax_rows(_p(scores), _p(out), scores.numel() // n, n, float(scale), _code(out_dtype),
-                                             _stream()))
-    return out
 
 
 # ------------------------------------------------------------------ elementwise
@@ -373,18 +364,6 @@ def silu(x):
     assert x.dtype == torch.float32 and x.is_contiguous()
     out = torch.empty_like(x)
     _lib.check(_lib.lib().sdamd_silu(_p(x), _p(out), x.numel(), _stream()))
-    return out
-
-
-def transpose_last2(x, cols=None):
-    """x [batch, rows, ld] (first ``cols`` columns used) -> [batch, cols, rows]."""
-    _dev(x)
-    assert x.dim() == 3 and x.stride(2) == 1
-    batch, rows, width = x.shape
-    cols = width if cols is None else cols
-    out = torch.empty((batch, cols, rows), dtype=x.dtype, device=x.device)
-    _lib.check(_lib.lib().sdamd_transpose(_p(x), _p(out), batch, rows, cols, x.stride(1), x.stride(0), cols * rows,
-                                          _code(x.dtype), _stream()))
     return out
 
 
@@ -499,8 +478,19 @@ def _stats_request(want, M, N, device):
 
 
 def _stats_attach(out, stats, wrote):
+    """Invariant: the statistics describe ``out`` as the launch stored it.  The version the tensor had then rides along
+    and ``groupnorm`` drops statistics whose tensor has since been written in place (a write through ``.data`` or
+    another view of the storage does not bump the version: nothing in the package writes a producer's result)."""
     if stats is not None and wrote._obj.value:
         out._sd_colstats = stats
+        out._sd_colstats_version = out._version
+
+
+def _stats_of(x):
+    st = getattr(x, "_sd_colstats", None)
+    if st is not None and getattr(x, "_sd_colstats_version", None) != x._version:
+        return None
+    return st
 
 
 F32_MODES = {"exact": 0, "bf16x3": 1}
@@ -529,6 +519,13 @@ def weight_planes(w):
     return planes
 
 
+def clear_weight_planes():
+    """Forget every cached bf16x3 weight plane (next to pipeline.clear_loop_cache / engine.clear_cache).  The cache is
+    keyed on the weight tensor's identity and ``_version``: call this after writing a weight through ``.data`` or
+    through another view of its storage, which bump neither."""
+    _W3.clear()
+
+
 def set_f32_mode(mode):
     """How fp32 GEMM / conv3x3 operands reach the matrix cores (include/sdamd.h, sdamd_set_f32_mode): "bf16x3" (default:
     three-term bf16 split, six MFMA products, f32-rounding-level accuracy) or "exact" (f32 MFMA, an fmaf chain over k).
@@ -552,19 +549,6 @@ def geglu_pack(t):
     v, g = t[:F2 // 2], t[F2 // 2:]
     tail = t.shape[1:]
     return torch.stack([v.reshape((F2 // 32, 16) + tail), g.reshape((F2 // 32, 16) + tail)], 1).reshape(t.shape).contiguous()
-
-
-def bmm_nt(a, b, out_f32=False):
-    """Batched a [Bt, M, K] @ b[Bt, N, K]^T -> [Bt, M, N] (both K-contiguous; a may be a strided row view)."""
-    _dev(a, b)
-    assert a.dim() == 3 and b.dim() == 3 and a.dtype == b.dtype and a.stride(2) == 1 and b.stride(2) == 1
-    Bt, M, K = a.shape
-    N = b.shape[1]
-    assert b.shape[0] == Bt and b.shape[2] == K
-    out = torch.empty((Bt, M, N), dtype=torch.float32 if out_f32 else a.dtype, device=a.device)
-    _lib.check(_lib.lib().sdamd_gemm(_p(a), _p(b), _p(out), 0, 0, M, N, K, a.stride(1), b.stride(1), N, 0, Bt, a.stride(0),
-                                     b.stride(0), M * N, 0, ACT_NONE, _code(a.dtype), int(out_f32), 0, 0, 0, None, 0, _stream()))
-    return out
 
 
 def conv3x3(x, w, bias, residual=None, stride=1, pad_mode=0, upsample=False, act=ACT_NONE, out_f32=False, flops_cin=None,
@@ -655,13 +639,3 @@ def attention(q, k, v, n_heads, causal=False, out=None):
                                                          _code(q.dtype), _stream())),
            f"B{B} H{n_heads} Sq{Sq} Skv{Skv} d{d}", (2 * B * Sq * C + 2 * B * Skv * C) * q.element_size())
     return out
-
-
-def attention_unfused(q, k, v):
-    """Single-head attention with a large head dim (VAE, d=512; decoder.py:43): QK^T and PV as
-    MFMA GEMMs around a row-softmax kernel.  q,k,v [B,S,C] column views of the fused projection."""
-    B, S, C = q.shape
-    scores = bmm_nt(q, k, out_f32=True)                       # [B,S,S] f32
-    probs = softmax_rows(scores, 1.0 / math.sqrt(C), q.dtype)  # [B,S,S]
-    vt = transpose_last2(v)                                    # [B,C,S]
-    return bmm_nt(probs, vt)                                   # [B,S,C]

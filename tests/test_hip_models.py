@@ -307,9 +307,46 @@ def test_denoise_steps_teacher_forced(models, dtype):
 
 
 def test_generate_graph_equals_eager(models):
-    a, la, _ = _gen(models, FP32, steps=3, use_graph=True)
+    """Three ways through the step loop, bit-equal: ONE hipGraph launch for the whole schedule (what generate() does
+    without a trace / preview), one-step graph replays, and eager launches."""
+    a, la, _ = _gen(models, FP32, steps=3, use_graph=True)         # (trace requested: one-step graph replays)
     b, lb, _ = _gen(models, FP32, steps=3, use_graph=False)
     assert torch.equal(la, lb) and np.array_equal(a, b)
+    pipeline.clear_loop_cache()
+    kw = dict(models=models, seed=42, device="cuda", sampler="ddpm", cfg_scale=7.5, steps=3, tokenizer=synth.SyntheticTokenizer(),
+              compute_dtype=FP32, return_latents=True)
+    c, lc = pipeline.generate("synthetic:0", "", **kw)
+    loop = next(reversed(pipeline._LOOP_CACHE.values()))[1]
+    assert loop.full_graph is not None and loop.host_step == loop.n_steps      # the whole loop went out as one launch
+    assert torch.equal(lc.cpu(), la[-1]) and np.array_equal(c, a)
+    c2, lc2 = pipeline.generate("synthetic:0", "", **kw)                       # replay of the cached whole-loop graph
+    assert torch.equal(lc2, lc) and np.array_equal(c2, c)
+    d, ld = pipeline.generate("synthetic:0", "", **{**kw, "cfg_scale": 3.0})   # another guidance scale: same captured graph,
+    assert len(pipeline._LOOP_CACHE) == 1 and not torch.equal(ld, lc)          # the scale rides in the coefficient table
+    pipeline.clear_loop_cache()
+    e, le = pipeline.generate("synthetic:0", "", **{**kw, "cfg_scale": 3.0, "use_graph": False})
+    assert torch.equal(ld, le) and np.array_equal(d, e)
+
+
+class _f32_mode:
+    def __init__(self, mode):
+        self.mode = mode
+
+    def __enter__(self):
+        self.old = ops.set_f32_mode(self.mode)
+        pipeline.clear_loop_cache()
+
+    def __exit__(self, *exc):
+        ops.set_f32_mode(self.old)
+        pipeline.clear_loop_cache()
+
+
+def test_exact_f32_mode_teacher_forced_and_50step_free_running(models):
+    """The `exact` fp32 mode (v_mfma_f32_16x16x4_f32; bench.py reports its step latency) through the whole pipeline:
+    per-step teacher-forced and the 50-step free-running run of BASELINE config 1 against the reference, fp32 budget."""
+    with _f32_mode("exact"):
+        test_denoise_steps_teacher_forced(models, FP32)
+        test_generate_txt2img_50step_vs_reference(models, FP32)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -439,6 +476,42 @@ def test_generate_768(models, dtype, monkeypatch):
         assert diff.max() <= 1 and (diff > 0).mean() < 0.01
     else:
         assert rel_l2(img.astype(np.float32), want_img.astype(np.float32)) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_generate_768_ten_steps_free_running(models, dtype, monkeypatch):
+    """Config 5's problem (768^2, latent 96x96) free-running over the first 10 steps of the 50-step schedule at batch 1,
+    every step's latents against the CPU oracle (the one-step test above cannot see error carried between steps)."""
+    for name, v in (("WIDTH", 768), ("HEIGHT", 768), ("LATENTS_WIDTH", 96), ("LATENT_HEIGHT", 96)):
+        monkeypatch.setattr(pipeline, name, v)
+    n = 10
+    sds = _cpu_sds(models)
+    if "g768x10" not in _ORACLE_CACHE:
+        toks = torch.tensor([synth.synthetic_token_ids(0), synth.EMPTY_PROMPT_IDS])
+        ctx = O.clip_forward(sds["clip"], toks)
+        samp = O.DDPMSampler(torch.Generator().manual_seed(42))
+        samp.set_steps(50)
+        lat = torch.randn((1, 4, 96, 96), generator=samp.generator)
+        tr = []
+        for t in samp.timesteps[:n]:
+            out = O.diffusion_forward(sds["diffusion"], lat.repeat(2, 1, 1, 1), ctx, O.get_time_embedding(int(t)))
+            lat = samp.step(int(t), lat, 7.5 * (out[0:1] - out[1:2]) + out[1:2])
+            tr.append(lat.clone())
+        _ORACLE_CACHE["g768x10"] = torch.stack(tr)
+    want = _ORACLE_CACHE["g768x10"]
+    # the product side: generate()'s own pieces, stopped after n of the 50 steps
+    for name, m in models.items():
+        with_dtype(m, FP32 if name == "clip" else dtype)
+    tok = synth.SyntheticTokenizer()
+    ctx = pipeline.encode_prompts(models["clip"], pipeline._token_tensor(tok, ["synthetic:0"], DEV), pipeline._token_tensor(tok, [""], DEV))
+    ts, coef, noise, lat0 = pipeline.prepare_latents([42], pipeline.DDPMSampler, 50, (1, 4, 96, 96), torch.device(DEV))
+    loop = pipeline.DenoiseLoop(models["diffusion"], ctx, ts, coef, noise, lat0, 7.5)
+    errs = []
+    for i in range(n):
+        loop.step()
+        errs.append(rel_l2(loop.latents.cpu(), want[i]))
+    print(f"\n[{dtype}] 768^2 free-running rel-L2, steps 1-{n}: " + " ".join(f"{e:.1e}" for e in errs))
+    assert max(errs) < TOL[dtype], errs
 
 
 @pytest.mark.parametrize("dtype", DTYPES)

@@ -270,9 +270,6 @@ def test_layout_roundtrip_and_embed(dtype):
     nhwc = ops.nchw_to_nhwc(x.to(DEV), dtype)
     assert torch.equal(nhwc.float().cpu(), x.permute(0, 2, 3, 1))
     assert torch.equal(ops.nhwc_to_nchw(nhwc).cpu(), x)
-    t = rnd("tr", (2, 70, 96)).to(dtype)
-    assert torch.equal(ops.transpose_last2(t.to(DEV), 40).cpu(),
-                       t[:, :, :40].transpose(1, 2).contiguous())
     table, pos = rnd("emb.t", (1000, 768)).to(dtype), rnd("emb.p", (77, 768)).to(dtype)
     ids = torch.randint(0, 1000, (2, 77), generator=torch.Generator().manual_seed(1))
     got = ops.clip_embed(ids.to(DEV), table.to(DEV), pos.to(DEV)).float().cpu()
@@ -292,12 +289,6 @@ def test_image_quantisation_and_vae_scalar_kernels():
     mean, logvar = F.conv2d(m, w8, b8).chunk(2, dim=1)
     want = (mean + logvar.clamp(-30, 20).exp().sqrt() * nz) * 0.18215
     assert rel_l2(ops.vae_sample(m.to(DEV), nz.to(DEV), w8.to(DEV), b8.to(DEV)).cpu(), want) < 1e-6
-
-
-def test_softmax_rows():
-    s = rnd("sm", (3, 50, 4096), 30.0)
-    want = F.softmax(s * 0.0442, dim=-1)
-    assert rel_l2(ops.softmax_rows(s.to(DEV), 0.0442, torch.float32).cpu(), want) < 2e-6
 
 
 # ------------------------------------------------------------------ MFMA GEMM
@@ -359,15 +350,26 @@ def test_gemm_fused_geglu(M, C):
     assert rel_l2(got.float().cpu(), want) <= rel_l2(unfused.float().cpu(), want) * 1.05
 
 
+def _bmm_nt(a, b):
+    """sdamd_gemm's batched form straight through the C ABI: a [Bt, M, K] @ b [Bt, N, K]^T -> f32 [Bt, M, N] (both
+    K-contiguous strided row views; no model uses it since the VAE head has a flash kernel, the ABI keeps it)."""
+    from sd_amd import _lib
+    Bt, M, K = a.shape
+    N = b.shape[1]
+    out = torch.empty((Bt, M, N), dtype=torch.float32, device=a.device)
+    _lib.check(_lib.lib().sdamd_gemm(a.data_ptr(), b.data_ptr(), out.data_ptr(), 0, 0, M, N, K, a.stride(1), b.stride(1), N, 0, Bt,
+                                     a.stride(0), b.stride(0), M * N, 0, ops.ACT_NONE, ops._code(a.dtype), 1, 0, 0, 0, None, 0,
+                                     torch.cuda.current_stream().cuda_stream))
+    return out
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_gemm_strided_views_and_batched(dtype, gemm_impl):
     qkv = q(rnd("bmm.qkv", (2, 192, 3 * 512)), dtype)
     d = qkv.to(dtype).to(DEV)
     qv, kv, vv = d[..., :512], d[..., 512:1024], d[..., 1024:]
     want = torch.einsum("bmk,bnk->bmn", qkv[..., :512].double(), qkv[..., 512:1024].double()).float()
-    assert rel_l2(ops.bmm_nt(qv, kv, out_f32=True).cpu(), want) < tol(dtype, 2e-6, 2e-5)
-    want_attn = O.attention_core(qkv[..., :512], qkv[..., 512:1024], qkv[..., 1024:], 1)
-    assert rel_l2(ops.attention_unfused(qv, kv, vv).float().cpu(), want_attn) < tol(dtype, 3e-6, 1e-2)
+    assert rel_l2(_bmm_nt(qv, kv).cpu(), want) < tol(dtype, 2e-6, 2e-5)
 
 
 # ------------------------------------------------------------------ implicit-GEMM conv
@@ -487,11 +489,14 @@ def test_conv_epilogue_column_stats_feed_groupnorm(dtype, B, H, Cin, Cout, res, 
     y = ops.conv3x3(x, w, b, r, 1, 0, False, out_f32=out_f32 and dtype != torch.float32, want_stats=True)
     M = B * H * H
     st = getattr(y, "_sd_colstats", None)
-    if st is None:
+    if dtype == torch.float32:
+        assert st is None      # f32-operand kernels never leave statistics (fp32 budget, see the offset-data test below)
+    if st is None and dtype != torch.float32:
         from sd_amd import _lib
         t = _lib.lib().sdamd_gemm_tile(M, Cout, 9 * Cin, 1, 0 if dtype == torch.float32 else 1, ops.GEMM_WS_BYTES, 0)
         assert t not in (128160, 128320, 256256, 256320), f"an un-split LDS-DMA launch (plan {t}) must produce the statistics"
-        # split-K (plan >= 1000000) or the register-staged kernels: no statistics, GroupNorm falls back to its own pass
+    if st is None:
+        # split-K (plan >= 1000000), the register-staged kernels or f32 operands: no statistics, GroupNorm falls back to its own pass
         gamma, beta = torch.ones(Cout, device=DEV), torch.zeros(Cout, device=DEV)
         got = ops.groupnorm(y, gamma, beta, 1e-5, False, out_dtype=dtype)
         ref = torch.nn.functional.group_norm(y.float().cpu().permute(0, 3, 1, 2), 32, eps=1e-5).permute(0, 2, 3, 1)
@@ -509,6 +514,37 @@ def test_conv_epilogue_column_stats_feed_groupnorm(dtype, B, H, Cin, Cout, res, 
         plain = y.clone()                                   # no statistics attached: the two-pass kernels
         want = ops.groupnorm(plain, gamma, beta, 1e-5, True, out_dtype=dtype)
         assert rel_l2(got.float().cpu(), want.float().cpu()) < tol(dtype, 2e-6, 4e-3)
+
+
+@pytest.mark.parametrize("offset", [0.0, 10.0, 100.0])
+def test_producer_stats_on_offset_data(offset, monkeypatch):
+    """The producer's partials are f32 sums of x and x^2 and the consumer forms E[x^2] - E[x]^2, so the statistics lose
+    accuracy as (mean / std)^2 * 2^-21.  Where that is allowed to matter: the bf16 mode only (f32 trunk, bf16 operands,
+    2e-2 budget) -- GroupNorm of a trunk with |mean| = 10 std and 100 std from producer statistics against the own-pass
+    (f64) kernel and float64; the fp32 mode (1e-4 budget) takes no producer statistics at all (f32 case: exact own pass
+    at a shape that crosses the models' 8 M-element threshold)."""
+    B, HW, C = 8, 4096, 320                                   # 10.5 M elements: above PRODUCER_STATS_MIN_ELEMS
+    a = rnd("off.a", (B, HW, C)).bfloat16().to(DEV)
+    w = (rnd("off.w", (C, C)) * C ** -0.5).bfloat16().to(DEV)
+    r = (rnd("off.r", (B, HW, C), 1.0) + offset).to(DEV)      # unit-scale data around `offset`
+    gamma, beta = (1.0 + 0.1 * rnd("off.g", (C,))).to(DEV), (0.1 * rnd("off.be", (C,))).to(DEV)
+    y = ops.gemm(a, w, None, r, out_f32=True, want_stats=True)
+    assert getattr(y, "_sd_colstats", None) is not None
+    got = ops.groupnorm(y, gamma, beta, 1e-5, False, out_dtype=torch.float32)
+    own = ops.groupnorm(y.clone(), gamma, beta, 1e-5, False, out_dtype=torch.float32)
+    ref = torch.nn.functional.group_norm(y.double().cpu().reshape(B, HW, C).permute(0, 2, 1), 32, gamma.double().cpu(),
+                                         beta.double().cpu(), 1e-5).permute(0, 2, 1)
+    e_pre, e_own = rel_l2(got.cpu().reshape(B, HW, C), ref), rel_l2(own.cpu().reshape(B, HW, C), ref)
+    print(f"\noffset {offset}: producer statistics {e_pre:.2e}, own pass {e_own:.2e}")
+    assert e_own < (2e-6 if offset <= 10.0 else 1e-5)      # (x - mean) in f32 at |x| = 100 std: 100 * 2^-24 of a std per element
+    assert e_pre < {0.0: 2e-6, 10.0: 5e-5, 100.0: 4e-3}[offset]     # bf16 operand rounding is 4e-3; 100 std is far outside the UNet's trunk
+    # fp32 mode: the same GEMM on f32 operands leaves no statistics, its GroupNorm is the exact own pass
+    y32 = ops.gemm(a.float(), w.float(), None, r, want_stats=True)
+    assert getattr(y32, "_sd_colstats", None) is None
+    g32 = ops.groupnorm(y32, gamma, beta, 1e-5, False)
+    ref32 = torch.nn.functional.group_norm(y32.double().cpu().reshape(B, HW, C).permute(0, 2, 1), 32, gamma.double().cpu(),
+                                           beta.double().cpu(), 1e-5).permute(0, 2, 1)
+    assert rel_l2(g32.cpu().reshape(B, HW, C), ref32) < (2e-6 if offset <= 10.0 else 1e-5)
 
 
 def test_gemm_epilogue_column_stats_and_virtual_concat(monkeypatch):
@@ -606,7 +642,7 @@ def test_flash_attention_d40_fixed_reference_fast_path_and_its_fallback():
 def test_flash_attention_vae_head_full_size_and_spiky(dtype):
     """decoder.py:39-70 at its real size (one head of 512, S = 4096 = the 64x64 map of a 512^2 image): strided views of
     the fused projection, one late dominant key (forces the online softmax of all four d-slice waves to rescale alike).
-    Checked against the CPU oracle on a slice of the queries and against the unfused GEMM / softmax / GEMM form."""
+    Checked against the CPU oracle on two slices of the queries."""
     B, S, C = 1, 4096, 512
     qkv = rnd("att.vae.full", (B, S, 3 * C), 0.5)
     qkv[:, 3000, C:2 * C] *= 6.0
@@ -616,8 +652,9 @@ def test_flash_attention_vae_head_full_size_and_spiky(dtype):
     rows = slice(1000, 1256)
     want = O.attention_core(qkv[:, rows, :C], qkv[..., C:2 * C], qkv[..., 2 * C:], 1)
     assert rel_l2(got[:, rows].float().cpu(), want) < tol(dtype, 3e-6, 1e-2)
-    unfused = ops.attention_unfused(dv[..., :C], dv[..., C:2 * C], dv[..., 2 * C:])
-    assert rel_l2(got.float().cpu(), unfused.float().cpu()) < tol(dtype, 5e-6, 1.5e-2)
+    rows = slice(3840, 4096)
+    want = O.attention_core(qkv[:, rows, :C], qkv[..., C:2 * C], qkv[..., 2 * C:], 1)
+    assert rel_l2(got[:, rows].float().cpu(), want) < tol(dtype, 3e-6, 1e-2)
 
 
 @pytest.mark.parametrize("impl", [0, 1, 2, 3])

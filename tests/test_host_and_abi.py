@@ -74,6 +74,20 @@ def test_rng_call_order_of_prepare_latents():
     assert coef.shape == (3, 8)
 
 
+@pytest.mark.parametrize("shape", [(1, 4, 64, 64), (1, 4, 3, 3), (1, 4, 2, 2)])
+def test_batched_step_noise_equals_draw_by_draw(shape):
+    """prepare_latents takes an image's per-step draws as one randn (threads over images): same stream as the
+    reference's call-by-call draws (ddpm.py:82), also on the sizes that take the sequential fallback (numel % 16 != 0)."""
+    seeds = [7, 8, 9]
+    ts, _, noise, lat = pipeline.prepare_latents(seeds, DDPMSampler, 5, shape, torch.device("cpu"))
+    for b, seed in enumerate(seeds):
+        g = torch.Generator().manual_seed(seed)
+        assert torch.equal(lat[b], torch.randn(shape[1:], generator=g))
+        for si, t in enumerate(ts):
+            want = torch.randn(shape[1:], generator=g) if int(t) > 0 else torch.zeros(shape[1:])
+            assert torch.equal(noise[si, b], want), (b, si)
+
+
 def test_synthetic_inputs_are_stable():
     ids = synth.synthetic_token_ids(0)
     assert len(ids) == 77 and ids[0] == synth.BOS and ids[-1] == synth.EOS and ids[:4] == [49406, 45205, 21483, 39265]
