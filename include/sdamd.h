@@ -158,6 +158,15 @@ int sdamd_gemm(const void* A, const void* W, void* C, const float* bias, const v
                long long strideW, long long strideC, long long strideR, int act, int dtype,
                int out_f32, void* ws, size_t ws_bytes, float* colstats, int* colstats_written,
                const void* w_planes, void* stream);
+/* diffusion.py:99-100, 110-117, 119-126 (conv_input -> layernorm_1; attention out_proj + residue -> layernorm_2 / _3):
+ * out [M][N] f32 = A [M][K] W[N][K]^T + bias (+ residual [M][N] f32, may be null), and from the same launch
+ * ln_out [M][N] bf16 = LayerNorm over each out row (biased variance, eps inside the sqrt) * ln_gamma + ln_beta, the
+ * bf16 operand of the next projection.  bf16 A / W, dense (ldw = K, ldc = ldr = N), N == 320: the 128x320 tile holds
+ * whole rows, so the f32 trunk is not read again by a LayerNorm launch.  Same arithmetic as sdamd_gemm followed by
+ * sdamd_layernorm (f32 in, bf16 out). */
+int sdamd_gemm_ln(const void* A, const void* W, float* out, const float* bias, const float* residual,
+                  void* ln_out, const float* ln_gamma, const float* ln_beta, float ln_eps, int M, int N,
+                  int K, int lda, void* stream);
 /* The weights of an f32 Linear / Conv2d (rows x K, K % 32 == 0, row stride ldw), split once into the three bf16
  * terms of the bf16x3 mode (sdamd_set_f32_mode): planes [rows][K/32][hi | mid | lo][32] bf16 = 6 bytes per weight,
  * the 32 k of a K-tile in the order the kernels' MFMA fragments take them.  No reference counterpart (a weight

@@ -1,0 +1,835 @@
+// 8-wave bf16 MFMA GEMM / implicit-GEMM conv3x3 for gfx950 with LDS-DMA staging.
+//
+//   out[m][n] = act( sum_k A[m][k] * W[n][k] + bias[n] + residual[m][n] )       (same contract as
+//   gemm_conv.hip; this file is the fast path for the bf16 problem sizes of the SD UNet / VAE)
+//
+// Workgroup = 512 threads = 8 waves (2 per SIMD) arranged WGM x WGN over a BM x BN output tile,
+// one workgroup per CU.  K-tile = 64 bf16 = 128 bytes per row.  Both operands are K-contiguous
+// and go global -> LDS directly with global_load_lds_dwordx4 (no VGPR round trip, no ds_write):
+// one wave-instruction lands 8 rows x 128 B = 1 KiB, lane l -> row l>>3, 16-byte chunk l&7.
+// The LDS image is linear per instruction, so the bank-conflict swizzle (chunk ^= (row>>1)&7,
+// conflict-free for the ds_read_b128 lane groups of the 16x16x32 MFMA operands) is applied to
+// the SOURCE chunk each lane fetches and again on the fragment reads.
+// Conv: the A row of output pixel m at K-tile (tap, c0) is 128 contiguous bytes of the NHWC
+// input (or of a zero page when the tap falls into the padding), so the gather is just a
+// per-lane source address; stride 1/2, symmetric or bottom/right padding and the fused nearest-2x
+// upsample are address arithmetic.
+// Pipeline: a ring of STAGES LDS buffers, one workgroup barrier per K-tile:
+//     wait until tile t has landed (counted vmcnt: tile t+1 .. t+STAGES-2 stay in flight)
+//     s_barrier          (tile t visible to every wave; every wave is done with tile t-1)
+//     issue the DMA of tile t+STAGES-1 into the buffer tile t-1 just vacated
+//     ds_read + MFMA on tile t
+// The barrier is a raw s_barrier with hand-counted s_waitcnt (a __syncthreads() would drain vmcnt to
+// 0 and serialise DMA and MFMA: measured, each alone runs at ~1.5 PF-equivalent, two stages with a
+// full drain per tile only reach 1.0-1.2).  The K loop is unrolled STAGES times so that buffer
+// addresses are compile-time.  MFMA "A" = weight rows, "B" = activation rows: a lane ends up with 4 consecutive
+// output channels of one row (vector bias / residual / store), as in gemm_conv.hip.
+#pragma once
+#include "gemm_common.h"
+#include <type_traits>
+#include <utility>
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void gbl_void_t;
+
+// 16-byte source for conv taps that fall into the zero padding
+static __device__ __attribute__((aligned(256))) const unsigned int g_zero_page[64] = {0};
+
+__device__ __forceinline__ int swz2(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() {
+  static_assert(N >= 0 && N < 64, "vmcnt range");
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// Timing ablations: p.debug 1 = no DMA, 2 = no MFMA (experiments only; sdamd_set_gemm_impl(debug << 8)).
+// For the dense GEMM instantiations they are compiled out unless -DSDAMD_GEMM_ABLATE: as runtime branches they
+// split the K-loop body and cost the 8-wave 128x320 tile 6-12 %.  The CONV and 4-wave instantiations keep the
+// (always false) runtime test on purpose: with it hipcc unswitches the K loop and keeps each tile's gather-address
+// arithmetic next to its DMA issue; without it the address arithmetic of two tiles is scheduled between the
+// MFMAs of one and the 4-wave conv tile drops from 800-930 to 560-620 TFLOP/s (same box,
+// experiments/ab_conv.py).
+#ifdef SDAMD_GEMM_ABLATE
+#define GEMM2_DBG(x) (p.debug == (x))
+#else
+#define GEMM2_DBG(x) ((CONV || WGM * WGN == 4) && p.debug == (x))
+#endif
+
+// EPI 0: every epilogue (split-K partials, GeGLU, f32 / hi|lo, operand type), chosen at run time.
+// EPI 1: the f32 / hi|lo epilogue with an f32 residual only, the residual prefetched ahead of the K loop.
+// EPI 2: the GeGLU epilogue only (bf16).
+// EPI 3: EPI 1 (the residual optional) + LayerNorm of the finished rows as a second, bf16 output (GemmArgs::ln_out): for
+//        tiles that hold whole rows (BN == N).  diffusion.py:110-117: out_proj + residue, then layernorm_2 of the sum.
+// (EPI 1 is a kernel of its own because a first build with the prefetch and every other epilogue in one kernel made
+// the launches WITHOUT a residual 6-13 us slower inside a UNet step, where consecutive launches are different
+// kernels, while a back-to-back microbenchmark saw nothing: code executed once per launch is not free.)
+// PP: the "ping-pong" main loop (see GEMM2 PING-PONG below); false = the one-barrier-per-K-tile ring of the header.
+template <typename T, int BM, int BN, int WGM, int WGN, int STAGES, bool CONV, int EPI, int PP>
+__device__ __forceinline__ void gemm2_body(const GemmArgs& p) {
+  constexpr bool F32 = sizeof(T) == 4;     // exact-f32 MFMA (v_mfma_f32_16x16x4_f32) on f32 operands
+  // f32 operands split into 3 bf16 terms, 6 bf16 MFMAs (split3_bf16).  WPL: the weight operand arrives split already
+  // (GemmArgs::W3, three bf16 planes of 32 k = 64 bytes per row and K-tile), so only the activation fragments are split
+  // in registers: TM instead of TM + TN fragment splits per K-tile (4 of 9 on the 128x160 tile, 2 of 7 on 64x160).
+  constexpr bool WPL = std::is_same<T, f32w_t>::value;
+  constexpr bool EMU = std::is_same<T, f32e_t>::value || WPL;
+  typedef typename std::conditional<WPL, bf16_t, T>::type TW;   // element type behind the W pointers
+  constexpr int EPC = 16 / sizeof(T);      // elements per 16-byte chunk
+  constexpr int BKE = 8 * EPC;             // K elements per 128-byte tile row (64 bf16 / 32 f32)
+  constexpr int NW = WGM * WGN;
+  constexpr int WTM = BM / WGM, WTN = BN / WGN;  // per-wave output tile
+  constexpr int TM = WTM / 16, TN = WTN / 16;    // 16x16 MFMA tiles per wave
+  // 1-KiB DMA pieces (8 rows) per K-tile: piece g of A (or B) belongs to wave g % NW; when the
+  // piece count does not divide, the last round is predicated on the (scalar) wave id
+  // (WPL: a 1-KiB piece of W is 16 rows x 64 bytes of one plane; plane p of 16-row block b is piece p*BN/16 + b)
+  constexpr int A_PIECES = BM / 8, B_PIECES = WPL ? 3 * (BN / 16) : BN / 8;
+  constexpr int A_INS = (A_PIECES + NW - 1) / NW, B_INS = (B_PIECES + NW - 1) / NW;
+  constexpr int MIN_PIECES = A_PIECES / NW + B_PIECES / NW;   // fewest pieces any wave issues per tile
+  constexpr int NPIECE = A_INS + B_INS;
+  constexpr int STAGE = BM * 128 + B_PIECES * 1024;
+  static_assert(BM % 8 == 0 && BN % 8 == 0 && WTM % 16 == 0 && WTN % 16 == 0 && STAGES >= 2 && STAGES <= 4, "tile shape");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  // XCD-aware (bijective) tile order, n fastest: an XCD's run of tiles shares A rows and the W panel
+  const int nwg = gridDim.x;
+  int bid = blockIdx.x;
+  {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int tn = bid % p.tiles_n, tm = bid / p.tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int batch = blockIdx.y;   // (split-K launches have batch == 1 and use blockIdx.z = split)
+  const T* __restrict__ A = (const T*)p.A + (size_t)batch * p.sA;
+  const TW* __restrict__ W = (const TW*)p.W + (size_t)batch * p.sW * (WPL ? 3 : 1);
+  // Phase-decomposed upsample conv (CONV, p.phase_up): "batch" is the output phase (py, px).  Output
+  // pixel (2y+py, 2x+px) of conv3x3(nearest2x(in)) only sees the 2x2 input window starting at
+  // (y-(1-py), x-(1-px)), with the 3x3 taps that land on the same input pixel pre-summed on the host:
+  // 4/9 of the MACs.  Rows m index the LOW-resolution grid; out_row() maps them to the output.
+  const bool phase_up = CONV && EPI == 0 && p.phase_up;   // (the phase form never carries a residual)
+  const int phase = batch + p.phase_base;
+  const int py = phase_up ? (phase >> 1) : 0, px = phase_up ? (phase & 1) : 0;
+  const int ntx = phase_up ? 2 : 3;                       // taps per filter row
+  auto out_row = [&](int m) -> size_t {
+    if (!phase_up) return (size_t)m;
+    const int hw = p.Ho * p.Wo;
+    const int n_img = m / hw, rem = m - n_img * hw;
+    const int y = rem / p.Wo, x = rem - y * p.Wo;
+    return ((size_t)n_img * 2 * p.Ho + 2 * y + py) * (2 * p.Wo) + 2 * x + px;
+  };
+
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int rr = lane >> 3, cl = lane & 7;
+
+  // per-lane DMA sources: piece i of this wave covers tile rows (wave + NW*i)*8 .. +7
+  const TW* wsrc[B_INS];
+#pragma unroll
+  for (int i = 0; i < B_INS; ++i) {
+    if constexpr (WPL) {
+      // lane l of a piece: row l>>2 of the 16-row block, 16-byte chunk l&3 of the 64-byte plane row; the chunk index is
+      // swizzled with (row>>2)&3 on the source so that the 16 rows a ds_read_b128 lane group touches cover all banks
+      const int g = min(wave + NW * i, B_PIECES - 1);
+      const int plane = g / (BN / 16), blk = g - plane * (BN / 16);
+      const int row = blk * 16 + (lane >> 2);
+      const int n = min(n0 + row, p.N - 1);
+      wsrc[i] = W + (size_t)n * 3 * p.K + plane * 32 + (((lane & 3) ^ ((row >> 2) & 3)) * 8);
+    } else {
+      const int row = min(wave + NW * i, B_PIECES - 1) * 8 + rr;
+      const int n = min(n0 + row, p.N - 1);
+      wsrc[i] = W + (size_t)n * p.ldw + (cl ^ ((row >> 1) & 7)) * EPC;
+    }
+  }
+  // A sources.  Dense: row pointer (+ swizzled chunk).  Conv: pointer to the top-left tap of the pixel's window
+  // (may lie outside the image) + a bit mask of the taps that are inside: per K-tile the gather address is then
+  // that pointer plus a wave-uniform (scalar) offset (ky*W + kx)*Cin + c0, and padding taps select the zero page.
+  // (The gathered nearest-2x form is not built here: launch_gemm2 sends it to gemm_conv.hip; the models use the
+  // phase form.)
+  const T* asrc[A_INS];
+  unsigned amask[A_INS];
+#pragma unroll
+  for (int i = 0; i < A_INS; ++i) {
+    const int row = min(wave + NW * i, A_PIECES - 1) * 8 + rr;
+    const int m = min(m0 + row, p.M - 1);
+    const int coff = (cl ^ ((row >> 1) & 7)) * EPC;
+    amask[i] = 0;
+    if (CONV) {
+      const int hw = p.Ho * p.Wo;
+      const int n_img = m / hw, rem = m - n_img * hw;
+      const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+      const int ay = oy * p.stride - (phase_up ? 1 - py : p.pad);
+      const int ax = ox * p.stride - (phase_up ? 1 - px : p.pad);
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+          if (ky < ntx && kx < ntx && (unsigned)(ay + ky) < (unsigned)p.H && (unsigned)(ax + kx) < (unsigned)p.Wd)
+            amask[i] |= 1u << (ky * ntx + kx);
+      asrc[i] = A + ((long long)n_img * p.H * p.Wd + (long long)ay * p.Wd + ax) * p.Cin + coff;
+    } else {
+      asrc[i] = A + (size_t)m * p.lda + coff;
+    }
+  }
+  const T* zsrc = reinterpret_cast<const T*>(g_zero_page) + cl * EPC;
+
+  // this workgroup's K-tiles: [kt_begin, kt_begin + nk)
+  const int nk_total = p.K / BKE;
+  const int split = blockIdx.z;
+  const int kt_begin = (int)((long long)nk_total * split / p.splits);
+  const int nk = (int)((long long)nk_total * (split + 1) / p.splits) - kt_begin;
+  int tap = 0, cc = 0;  // conv K position of the next tile to stage: filter tap, channel offset
+  if (CONV) { const int kpt = p.Cin / BKE; tap = kt_begin / kpt; cc = (kt_begin - tap * kpt) * BKE; }
+  // DMA piece PI (compile-time) of the tile at K offset k0 / conv position (ky, kx, cc)
+  auto stage_piece = [&](auto PIC, char* stage, int k0, int ky, int kx) {
+    constexpr int PI = decltype(PIC)::value;
+    if constexpr (PI < A_INS) {
+      constexpr int i = PI;
+      if (A_PIECES % NW != 0 && i == A_INS - 1 && wave + NW * i >= A_PIECES) return;
+#ifdef SDAMD_FILL_ABLATE   // timing experiment (wrong results): the activation tile is only fetched for tap (0, 0) = A fill / 9
+      if (CONV && p.debug == 3 && (ky | kx)) return;
+#endif
+      const T* g;
+      if (CONV) {
+        const int delta = __builtin_amdgcn_readfirstlane((ky * p.Wd + kx) * p.Cin + cc);   // wave-uniform
+        g = ((amask[i] >> __builtin_amdgcn_readfirstlane(ky * ntx + kx)) & 1u) ? asrc[i] + delta : zsrc;
+      } else {
+        g = asrc[i] + k0;
+      }
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)g, (lds_void_t*)(stage + (wave + NW * i) * 1024), 16, 0, 0);
+    } else {
+      constexpr int i = PI - A_INS;
+      if (B_PIECES % NW != 0 && i == B_INS - 1 && wave + NW * i >= B_PIECES) return;
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)(wsrc[i] + k0 * (WPL ? 3 : 1)), (lds_void_t*)(stage + BM * 128 + (wave + NW * i) * 1024), 16, 0, 0);
+    }
+  };
+  auto advance_k = [&]() { if (CONV) { cc += BKE; if (cc >= p.Cin) { cc = 0; ++tap; } } };
+  auto stage_tile = [&](char* stage, int k0) {   // all pieces back to back (prologue)
+    if (GEMM2_DBG(1)) return;
+    int ky = 0, kx = 0;
+    if (CONV) { ky = tap / ntx; kx = tap - ky * ntx; }
+    [&]<int... PI>(std::integer_sequence<int, PI...>) { (stage_piece(std::integral_constant<int, PI>{}, stage, k0, ky, kx), ...); }
+    (std::make_integer_sequence<int, NPIECE>{});
+    advance_k();
+  };
+
+  f32x4_t acc[TN][TM];
+#pragma unroll
+  for (int j = 0; j < TN; ++j)
+#pragma unroll
+    for (int i = 0; i < TM; ++i) acc[j][i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  const int r16 = lane & 15, q4 = lane >> 4;
+  // MFMAs of one K-tile; optionally (INTERLEAVE_DMA) with the DMA pieces of a later tile spread
+  // between the MFMA groups instead of issued back to back ahead of them.  Measured: no gain on the
+  // 8-wave tiles and -25 % on the 4-wave 128x160 tile, so it is off; the limiter of the K loop is the
+  // L2 -> LDS fill rate (~60 GB/s per CU), i.e. bytes per FLOP, i.e. the tile size.
+  constexpr bool INTERLEAVE_DMA = false;
+  auto compute_tile = [&](const char* stage, char* next_stage, bool do_stage, int k0) {
+    const char* sa = stage;
+    const char* sw = stage + BM * 128;
+    int ky = 0, kx = 0;
+    if (CONV) { ky = tap / ntx; kx = tap - ky * ntx; }
+    if (GEMM2_DBG(1)) do_stage = false;
+    constexpr int NGROUP = 2 * TN;
+    // one 16-byte fragment per lane and tile: 8 bf16 (one 16x16x32 MFMA) or 4 f32 (four 16x16x4
+    // MFMAs; the k order inside the group is permuted alike for both operands)
+    typedef typename std::conditional<F32, f32x4_t, bf16x8_t>::type frag_t;
+    // The two K halves (g) of the tile use separate fragment registers and the reads of half 1 are
+    // issued before the MFMAs of half 0 (sched_barriers pin that order): left to itself hipcc
+    // re-uses one register quad and emits "ds_read; s_waitcnt lgkmcnt(0); 4 MFMAs" ten times per
+    // tile, i.e. an exposed LDS latency every 64 MFMA cycles.
+    // Measured (same box, experiments/gemm_bench.py): +3-9 % on the 8-wave 128x320 tile, -35 % on the 4-wave
+    // 128x160 tile (two workgroups per CU: its waves interleave best at the compiler's fine grain), so 8 waves only.
+    constexpr bool PREFETCH = !INTERLEAVE_DMA && !EMU && NW == 8 && (TM + TN) <= 9;
+    frag_t xf[2][TM], wf[2][TN];
+    auto load_frags = [&](int g) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) xf[g][i] = *reinterpret_cast<const frag_t*>(sa + swz2(wm * WTM + i * 16 + r16, 4 * g + q4));
+#pragma unroll
+      for (int j = 0; j < TN; ++j) wf[g][j] = *reinterpret_cast<const frag_t*>(sw + swz2(wn * WTN + j * 16 + r16, 4 * g + q4));
+    };
+    if constexpr (PREFETCH) {
+      load_frags(0);
+      __builtin_amdgcn_sched_barrier(0);
+      load_frags(1);
+      // one scheduling region = [reads of half 1 | MFMAs of half 0], pinned to "1 ds_read, then a few MFMAs":
+      // the reads ride under the matrix pipe instead of bursting (a burst of all 18 reads with every wave of
+      // the workgroup behind the same barrier measured 40 % slower on the 4-wave tile)
+      constexpr int NRD = TM + TN, NMF = TM * TN * (F32 ? 4 : 1), PER = NMF / NRD;
+#pragma unroll
+      for (int r = 0; r < NRD; ++r) {
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);     // DS read
+        __builtin_amdgcn_sched_group_barrier(0x008, PER, 0);   // MFMA
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, NMF - PER * NRD, 0);
+    }
+    if constexpr (EMU) {
+      if constexpr (WPL) {
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+          for (int i = 0; i < TM; ++i) xf[g][i] = *reinterpret_cast<const frag_t*>(sa + swz2(wm * WTM + i * 16 + r16, 4 * g + q4));
+      } else {
+        load_frags(0);
+        load_frags(1);
+      }
+      bf16x8_t xh[TM], xm[TM], xl[TM];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) split3_bf16(xf[0][i], xf[1][i], xh[i], xm[i], xl[i]);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        bf16x8_t wh, wmid, wl;
+        if constexpr (WPL) {   // (sdamd_split3_weights stores the 32 k of a tile in the fragment order of the f32 reads)
+          const char* wb = sw + ((wn * WTN + j * 16) >> 4) * 1024 + r16 * 64 + ((q4 ^ ((r16 >> 2) & 3)) << 4);
+          wh = *reinterpret_cast<const bf16x8_t*>(wb);
+          wmid = *reinterpret_cast<const bf16x8_t*>(wb + (BN / 16) * 1024);
+          wl = *reinterpret_cast<const bf16x8_t*>(wb + 2 * (BN / 16) * 1024);
+        } else {
+          split3_bf16(wf[0][j], wf[1][j], wh, wmid, wl);
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {   // small terms first
+          acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, xh[i], acc[j][i], 0, 0, 0);
+          acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xl[i], acc[j][i], 0, 0, 0);
+          acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wmid, xm[i], acc[j][i], 0, 0, 0);
+          acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wmid, xh[i], acc[j][i], 0, 0, 0);
+          acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xm[i], acc[j][i], 0, 0, 0);
+          acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh[i], acc[j][i], 0, 0, 0);
+        }
+      }
+    } else
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      if constexpr (!PREFETCH) load_frags(g);
+      [&]<int... J>(std::integer_sequence<int, J...>) {
+        ([&] {
+          constexpr int j = J;
+          if (!GEMM2_DBG(2)) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+              if constexpr (F32) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[g][j][e], xf[g][i][e], acc[j][i], 0, 0, 0);
+              } else {
+                acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[g][j], xf[g][i], acc[j][i], 0, 0, 0);
+              }
+            }
+          }
+          // pieces assigned to MFMA group q = g*TN + j: those with PI*NGROUP/NPIECE == q
+          [&]<int... PI>(std::integer_sequence<int, PI...>) {
+            ([&] {
+              if constexpr (PI * NGROUP / NPIECE == 0 * TN + j) { if (g == 0 && do_stage) stage_piece(std::integral_constant<int, PI>{}, next_stage, k0, ky, kx); }
+              if constexpr (PI * NGROUP / NPIECE == 1 * TN + j) { if (g == 1 && do_stage) stage_piece(std::integral_constant<int, PI>{}, next_stage, k0, ky, kx); }
+            }(), ...);
+          }(std::make_integer_sequence<int, NPIECE>{});
+        }(), ...);
+      }(std::make_integer_sequence<int, TN>{});
+      if constexpr (PREFETCH) __builtin_amdgcn_sched_barrier(0);
+    }
+    if (do_stage) advance_k();
+  };
+
+  // main loop (see the header): tile t lives in ring buffer t % STAGES
+#define GEMM2_STEP(BUF, NEXTBUF)                                                         \
+  {                                                                                      \
+    if (kt + STAGES - 1 <= nk) wait_vmcnt<(STAGES - 2) * MIN_PIECES>(); else wait_vmcnt<0>(); \
+    __builtin_amdgcn_s_barrier();                                                        \
+    if (INTERLEAVE_DMA) {                                                                \
+      compute_tile(smem + (BUF) * STAGE, smem + (NEXTBUF) * STAGE, kt + STAGES - 1 < nk, (kt_begin + kt + STAGES - 1) * BKE); \
+    } else {                                                                             \
+      if (kt + STAGES - 1 < nk) stage_tile(smem + (NEXTBUF) * STAGE, (kt_begin + kt + STAGES - 1) * BKE); \
+      compute_tile(smem + (BUF) * STAGE, nullptr, false, 0);                             \
+    }                                                                                    \
+    if (++kt >= nk) break;                                                               \
+  }
+  int kt = 0;
+  // ---- GEMM2 PING-PONG (PP): 8 waves = two groups of 4 (waves 0-3 / 4-7: the two waves of every SIMD are in different
+  // groups), 2M x 4N wave grid, 2-stage ring.  A K-tile is four phases, one per quadrant of the wave's sub-tile
+  //   p0: read A0, B0 fragments -> MFMA C[B0][A0]      p1: read B1 -> C[B1][A0]
+  //   p2: read A1               -> MFMA C[B1][A1]      p3: re-read B0 -> C[B0][A1]
+  // and a phase is [LDS reads + the DMA issue of a quarter of the NEXT tile] s_barrier [MFMA cluster] s_barrier.  Group 1
+  // runs one barrier behind group 0 (one extra s_barrier before the loop), so on every SIMD one wave is in its MFMA
+  // cluster while its partner is in its read / DMA-issue segment: the matrix pipe sees a dense MFMA stream and the LDS
+  // reads never stand in front of it (MI355X_MICROARCH.md "Two waves per SIMD").  DMA of tile t+1 (into the other ring
+  // buffer) by phase of tile t, per wave: p0 the A pieces with even index (rows of every wave's A0 half), p1 / p2 the W
+  // pieces, p3 the odd A pieces (A1 halves).  Counted waits, never zero in the loop: at the end of p3's read segment
+  // vmcnt(A1 pieces) retires A0 + W of tile t+1 (first read two barriers later, in p0 of t+1, also for the lagging
+  // group); at the end of p1's read segment vmcnt(everything issued after A1(t)) retires A1 of the CURRENT tile (read in
+  // p2).  WAR: a ring buffer's rows are re-staged no earlier than two phases after their last read by either group.
+  constexpr int PP_TMH = TM / 2, PP_TN0 = (TN + 1) / 2, PP_TN1 = TN - PP_TN0;
+  constexpr int PP_WA = B_INS / 2;                       // W pieces issued in p1 (the rest in p2)
+  typedef typename std::conditional<F32, f32x4_t, bf16x8_t>::type ppfrag_t;
+  [[maybe_unused]] auto pp_issue = [&](auto LO, auto HI, auto STEP, char* stage, int k0, int ky, int kx) {   // pieces LO, LO+STEP, ... < HI
+    constexpr int lo = decltype(LO)::value, hi = decltype(HI)::value, st = decltype(STEP)::value;
+    if (GEMM2_DBG(1)) return;
+    [&]<int... Q>(std::integer_sequence<int, Q...>) {
+      (stage_piece(std::integral_constant<int, lo + Q * st>{}, stage, k0, ky, kx), ...);
+    }(std::make_integer_sequence<int, (hi - lo + st - 1) / st>{});
+  };
+  if constexpr (PP) {
+    static_assert(NW == 8 && WGM == 2 && STAGES == 2 && TM % 2 == 0 && !F32 && !EMU, "ping-pong: 8 waves as 2M x 4N, bf16, 2-stage ring");
+    static_assert(A_PIECES % NW == 0 && B_PIECES % NW == 0 && A_INS % 2 == 0 && B_INS >= 2, "ping-pong: uniform DMA piece counts per wave");
+    int ky = 0, kx = 0;
+    if (CONV) { ky = tap / ntx; kx = tap - ky * ntx; }
+    const int k0 = kt_begin * BKE;
+    pp_issue(std::integral_constant<int, 0>{}, std::integral_constant<int, A_INS>{}, std::integral_constant<int, 2>{}, smem, k0, ky, kx);           // A0 halves
+    pp_issue(std::integral_constant<int, A_INS>{}, std::integral_constant<int, NPIECE>{}, std::integral_constant<int, 1>{}, smem, k0, ky, kx);     // W
+    pp_issue(std::integral_constant<int, 1>{}, std::integral_constant<int, A_INS>{}, std::integral_constant<int, 2>{}, smem, k0, ky, kx);           // A1 halves
+    advance_k();
+  } else {
+    stage_tile(smem, kt_begin * BKE);
+#pragma unroll
+    for (int s = 1; s < STAGES - 1; ++s)
+      if (nk > s) stage_tile(smem + s * STAGE, (kt_begin + s) * BKE);
+  }
+  // f32 residual prefetch: the epilogue's residual chunks (same (m, n) per lane as its row-segment stores) are
+  // requested here, behind the first K-tile's DMA, so the fetch overlaps the K loop instead of standing between
+  // the last MFMA and the first store -- the short-K GEMMs on the f32 trunk are bound by exactly those bytes.
+  // Only where the 80 extra registers fit beside two waves per SIMD (launch2 picks EPI accordingly).
+  constexpr bool RPRE = EPI == 1 || EPI == 3;
+  constexpr bool LNF = EPI == 3;
+  constexpr int E_CPR = WTN / 4;                          // 16-byte chunks per sub-tile row (f32 epilogue)
+  constexpr int E_RS = WTN * 4 + 16;
+  constexpr int E_IPMAX = (STAGES * STAGE / NW) / (16 * E_RS);
+  constexpr int E_IP = E_IPMAX >= TM ? TM : (E_IPMAX >= TM / 2 && TM % 2 == 0) ? TM / 2 : (E_IPMAX >= TM / 4 && TM % 4 == 0) ? TM / 4 : 1;
+  constexpr int E_IT = E_IP * 16 * E_CPR / 64;            // chunks per lane and pass
+  static_assert(!RPRE || (E_IP * 16 * E_CPR) % 64 == 0, "residual prefetch expects whole lane rounds");
+  f32x4_t rpre[RPRE ? (TM / E_IP) * E_IT : 1];
+  if constexpr (RPRE) {
+    // (the always-true run-time test keeps the block a region of its own: scheduled together with the prologue
+    // the 20 address computations stay live across it and the kernel spills)
+    if (p.R) {
+      const float* __restrict__ Rf = (const float*)p.R + (size_t)batch * p.sR;
+      const int mw = m0 + wm * WTM, nw = n0 + wn * WTN;
+#pragma unroll
+      for (int ps = 0; ps < TM / E_IP; ++ps)
+#pragma unroll
+        for (int it = 0; it < E_IT; ++it) {
+          const int idx = lane + it * 64;
+          const int row = idx / E_CPR, ch = idx - row * E_CPR;
+          const int m = mw + ps * E_IP * 16 + row, n = nw + ch * 4;
+          rpre[ps * E_IT + it] = (m < p.M && n < p.N) ? *reinterpret_cast<const f32x4_t*>(Rf + out_row(m) * p.ldr + n) : (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        }
+    } else if constexpr (LNF) {   // (EPI 1 is only launched with a residual)
+#pragma unroll
+      for (int k = 0; k < (TM / E_IP) * E_IT; ++k) rpre[k] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  if constexpr (PP) {
+    ppfrag_t xa[2][PP_TMH], wb0[2][PP_TN0], wb1[2][PP_TN1 > 0 ? PP_TN1 : 1];
+    auto ld_a = [&](const char* sa, int half) {
+#pragma unroll
+      for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int i = 0; i < PP_TMH; ++i)
+          xa[g][i] = *reinterpret_cast<const ppfrag_t*>(sa + swz2(wm * WTM + (half * PP_TMH + i) * 16 + r16, 4 * g + q4));
+    };
+    auto ld_b0 = [&](const char* sw) {
+#pragma unroll
+      for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int j = 0; j < PP_TN0; ++j)
+          wb0[g][j] = *reinterpret_cast<const ppfrag_t*>(sw + swz2(wn * WTN + j * 16 + r16, 4 * g + q4));
+    };
+    auto ld_b1 = [&](const char* sw) {
+#pragma unroll
+      for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int j = 0; j < PP_TN1; ++j)
+          wb1[g][j] = *reinterpret_cast<const ppfrag_t*>(sw + swz2(wn * WTN + (PP_TN0 + j) * 16 + r16, 4 * g + q4));
+    };
+    // MFMA cluster of one quadrant: B half `bh` (0: wb0, 1: wb1) x A half `ah`
+    auto mm = [&](auto BH, int ah) {
+      constexpr int bh = decltype(BH)::value;
+      constexpr int nj = bh ? PP_TN1 : PP_TN0;
+      if (GEMM2_DBG(2)) return;
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int j = 0; j < nj; ++j)
+#pragma unroll
+          for (int i = 0; i < PP_TMH; ++i) {
+            if constexpr (bh) acc[PP_TN0 + j][ah * PP_TMH + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb1[g][j], xa[g][i], acc[PP_TN0 + j][ah * PP_TMH + i], 0, 0, 0);
+            else acc[j][ah * PP_TMH + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb0[g][j], xa[g][i], acc[j][ah * PP_TMH + i], 0, 0, 0);
+          }
+      __builtin_amdgcn_s_setprio(0);
+    };
+    using C0 = std::integral_constant<int, 0>;
+    using C1 = std::integral_constant<int, 1>;
+    // prologue wait: A0 + W of tile 0 landed (its A1 pieces stay in flight), visible to every wave
+    wait_vmcnt<A_INS / 2>();
+    __builtin_amdgcn_s_barrier();
+    if (wm == 1) __builtin_amdgcn_s_barrier();        // group 1 runs one barrier behind group 0
+    // PP = 1: the B0 fragments stay in registers from p0 to p3; 2: they are re-read in p3 (16 VGPRs fewer on the 256x256
+    // tile; measured 0-3 % slower, experiments/pp_bench.py).  Issuing the DMA ahead of the reads, or dropping the
+    // s_setprio pair, measured the same within noise.
+    constexpr bool DMA_FIRST = false, KEEP_B0 = PP == 1;
+#define GEMM2_PP_TILE(BUF, NEXTBUF)                                                                        \
+    {                                                                                                      \
+      const char* sa = smem + (BUF) * STAGE;                                                               \
+      const char* sw = sa + BM * 128;                                                                      \
+      char* nx = smem + (NEXTBUF) * STAGE;                                                                 \
+      const bool hn = kt + 1 < nk;                                                                         \
+      const int k0n = (kt_begin + kt + 1) * BKE;                                                           \
+      int ky = 0, kx = 0;                                                                                  \
+      if (CONV) { ky = tap / ntx; kx = tap - ky * ntx; }                                                   \
+      /* p0 */                                                                                             \
+      if (!DMA_FIRST) { ld_a(sa, 0); ld_b0(sw); }                                                          \
+      if (hn) pp_issue(C0{}, std::integral_constant<int, A_INS>{}, std::integral_constant<int, 2>{}, nx, k0n, ky, kx); \
+      if (DMA_FIRST) { ld_a(sa, 0); ld_b0(sw); }                                                           \
+      __builtin_amdgcn_sched_barrier(0);                                                                   \
+      __builtin_amdgcn_s_barrier();                                                                        \
+      mm(C0{}, 0);                                                                                         \
+      __builtin_amdgcn_sched_barrier(0);                                                                   \
+      __builtin_amdgcn_s_barrier();                                                                        \
+      /* p1 */                                                                                             \
+      if (!DMA_FIRST) ld_b1(sw);                                                                           \
+      if (hn) pp_issue(std::integral_constant<int, A_INS>{}, std::integral_constant<int, A_INS + PP_WA>{}, C1{}, nx, k0n, ky, kx); \
+      if (DMA_FIRST) ld_b1(sw);                                                                            \
+      if (hn) wait_vmcnt<A_INS / 2 + PP_WA>(); else wait_vmcnt<0>();                                       \
+      __builtin_amdgcn_sched_barrier(0);                                                                   \
+      __builtin_amdgcn_s_barrier();                                                                        \
+      mm(C1{}, 0);                                                                                         \
+      __builtin_amdgcn_sched_barrier(0);                                                                   \
+      __builtin_amdgcn_s_barrier();                                                                        \
+      /* p2 */                                                                                             \
+      if (!DMA_FIRST) ld_a(sa, 1);                                                                         \
+      if (hn) pp_issue(std::integral_constant<int, A_INS + PP_WA>{}, std::integral_constant<int, NPIECE>{}, C1{}, nx, k0n, ky, kx); \
+      if (DMA_FIRST) ld_a(sa, 1);                                                                          \
+      __builtin_amdgcn_sched_barrier(0);                                                                   \
+      __builtin_amdgcn_s_barrier();                                                                        \
+      mm(C1{}, 1);                                                                                         \
+      __builtin_amdgcn_sched_barrier(0);                                                                   \
+      __builtin_amdgcn_s_barrier();                                                                        \
+      /* p3 */                                                                                             \
+      if (!DMA_FIRST && !KEEP_B0) ld_b0(sw);                                                               \
+      if (hn) {                                                                                            \
+        pp_issue(C1{}, std::integral_constant<int, A_INS>{}, std::integral_constant<int, 2>{}, nx, k0n, ky, kx); \
+        advance_k();                                                                                       \
+      }                                                                                                    \
+      if (DMA_FIRST && !KEEP_B0) ld_b0(sw);                                                                \
+      if (hn) wait_vmcnt<A_INS / 2>();                                                                     \
+      __builtin_amdgcn_sched_barrier(0);                                                                   \
+      __builtin_amdgcn_s_barrier();                                                                        \
+      mm(C0{}, 1);                                                                                         \
+      __builtin_amdgcn_sched_barrier(0);                                                                   \
+      __builtin_amdgcn_s_barrier();                                                                        \
+      if (++kt >= nk) break;                                                                               \
+    }
+    for (;;) {
+      GEMM2_PP_TILE(0, 1)
+      GEMM2_PP_TILE(1, 0)
+    }
+#undef GEMM2_PP_TILE
+    if (wm == 0) __builtin_amdgcn_s_barrier();        // group 0 catches up: every wave has passed the same number of barriers
+  } else if (STAGES == 2) {
+    for (;;) {
+      GEMM2_STEP(0, 1)
+      GEMM2_STEP(1, 0)
+    }
+  } else if (STAGES == 3) {
+    for (;;) {
+      GEMM2_STEP(0, 2)
+      GEMM2_STEP(1, 0)
+      GEMM2_STEP(2, 1)
+    }
+  } else {
+    for (;;) {
+      GEMM2_STEP(0, 3)
+      GEMM2_STEP(1, 0)
+      GEMM2_STEP(2, 1)
+      GEMM2_STEP(3, 2)
+    }
+  }
+#undef GEMM2_STEP
+
+  if (EPI == 0 && p.splits > 1) {  // raw f32 partial sums; bias / residual / activation happen in splitk_reduce_kernel
+    float* __restrict__ ws = p.ws + (size_t)split * p.M * p.N;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int m = m0 + wm * WTM + i * 16 + r16;
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * WTN + j * 16 + q4 * 4;
+        if (n >= p.N) continue;
+        *reinterpret_cast<f32x4_t*>(ws + (size_t)m * p.N + n) = acc[j][i];
+      }
+    }
+    return;
+  }
+
+  // Epilogue.  A lane holds out[m][n..n+3] for 4 x TM x TN scattered (m, n): stored directly that is
+  // 8-16 bytes per lane at a row stride, which is store-issue bound (measured: the K=320 GEMMs spent
+  // more time here than in the K loop).  Instead every wave transposes its WTM x WTN sub-tile
+  // through its own slice of the (now idle) staging LDS and writes whole row segments, 16 bytes per
+  // lane, consecutive lanes on consecutive addresses.  No workgroup barrier is needed after the one
+  // below: a wave only reads back what it wrote itself, and LDS operations of one wave complete in
+  // order.
+  __syncthreads();  // every wave is done reading the last K-tile (and no DMA is outstanding)
+  const float* __restrict__ bias = p.bias;
+  const int mw = m0 + wm * WTM, nw = n0 + wn * WTN;  // this wave's sub-tile origin
+  if (EPI == 2 || (EPI == 0 && !F32 && p.act == ACT_GEGLU)) {
+    // GeGLU epilogue (diffusion.py:128-130): the weight rows were packed so that 16-column tile 2c
+    // holds the value channels [16c, 16c+16) and tile 2c+1 their gates; value * gelu_erf(gate) is
+    // lane-local on the f32 accumulators and only the N/2 products are rounded and stored (bf16).
+    if constexpr (TN % 2 == 0) {
+      constexpr int WTO = WTN / 2;                         // output columns of this wave
+      constexpr int RS = WTO * 2 + 16;
+      constexpr int IPMAX = (STAGES * STAGE / NW) / (16 * RS);
+      constexpr int IP = IPMAX >= TM ? TM : (IPMAX >= TM / 2 && TM % 2 == 0) ? TM / 2 : (IPMAX >= TM / 4 && TM % 4 == 0) ? TM / 4 : 1;
+      static_assert(IPMAX >= 1, "epilogue staging does not fit");
+      constexpr int CPR = WTO / 8;
+      char* const slice = smem + wave * (IP * 16 * RS);
+      bf16_t* __restrict__ C = (bf16_t*)p.C + (size_t)batch * p.sC;
+      const int nwo = (n0 >> 1) + wn * WTO;                // first output column of this wave
+#pragma unroll
+      for (int ps = 0; ps < TM / IP; ++ps) {
+#pragma unroll
+        for (int ii = 0; ii < IP; ++ii) {
+#pragma unroll
+          for (int j = 0; j < TN; j += 2) {
+            f32x4_t v = acc[j][ps * IP + ii], g = acc[j + 1][ps * IP + ii];
+            const int n = nw + j * 16 + q4 * 4;
+            if (bias && n + 16 < p.N) {
+              v += *reinterpret_cast<const f32x4_t*>(bias + n);
+              g += *reinterpret_cast<const f32x4_t*>(bias + n + 16);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] *= gelu_erf_f(g[r]);
+            const u32x2_t o = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+            *reinterpret_cast<u32x2_t*>(slice + (ii * 16 + r16) * RS + ((j >> 1) * 16 + q4 * 4) * 2) = o;
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (int idx = lane; idx < IP * 16 * CPR; idx += 64) {
+          const int row = idx / CPR, ch = idx - row * CPR;
+          const int m = mw + ps * IP * 16 + row, n = nwo + ch * 8;
+          const u32x4_t v = *reinterpret_cast<const u32x4_t*>(slice + row * RS + ch * 16);
+          if (m < p.M && n < (p.N >> 1)) *reinterpret_cast<u32x4_t*>(C + out_row(m) * p.ldc + n) = v;
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+  } else if (EPI != 2 && (RPRE || F32 || p.out_f32)) {
+    constexpr int RS = WTN * 4 + 16;                     // padded LDS row stride (bytes)
+    constexpr int IPMAX = (STAGES * STAGE / NW) / (16 * RS);  // 16-row tiles per pass that fit the wave's slice
+    constexpr int IP = IPMAX >= TM ? TM : (IPMAX >= TM / 2 && TM % 2 == 0) ? TM / 2 : (IPMAX >= TM / 4 && TM % 4 == 0) ? TM / 4 : 1;
+    static_assert(IPMAX >= 1, "epilogue staging does not fit");
+    constexpr int CPR = WTN / 4;  // 16-byte chunks per row
+    static_assert(WTM % 64 != 0 || 64 % (IP * 16) == 0, "column statistics: an epilogue pass must not span two 64-row blocks");
+    char* const slice = smem + wave * (IP * 16 * RS);
+    const float* __restrict__ Rf = p.R ? (const float*)p.R + (size_t)batch * p.sR : nullptr;
+    float* __restrict__ C = (float*)p.C + (size_t)batch * p.sC;
+    // column statistics of the stored values for a following GroupNorm (GemmArgs::colstats): the finished chunks go
+    // back into the wave's LDS slice and every lane then sums one (or two) columns over the pass's rows
+    const bool do_stats = p.colstats != nullptr;
+    constexpr int NCR = (WTN + 63) / 64;
+    float cs[NCR], cq[NCR];
+#pragma unroll
+    for (int k = 0; k < NCR; ++k) { cs[k] = 0.f; cq[k] = 0.f; }
+#pragma unroll
+    for (int ps = 0; ps < TM / IP; ++ps) {
+#pragma unroll
+      for (int ii = 0; ii < IP; ++ii) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          f32x4_t v = acc[j][ps * IP + ii];
+          const int n = nw + j * 16 + q4 * 4;
+          if (bias && n < p.N) v += *reinterpret_cast<const f32x4_t*>(bias + n);
+          *reinterpret_cast<f32x4_t*>(slice + (ii * 16 + r16) * RS + (j * 16 + q4 * 4) * 4) = v;
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      auto finish = [&](int idx, f32x4_t r, bool have_r) {   // row-segment chunk idx of this pass: residual, activation, store
+        const int row = idx / CPR, ch = idx - row * CPR;
+        const int m = mw + ps * IP * 16 + row, n = nw + ch * 4;
+        f32x4_t v = *reinterpret_cast<const f32x4_t*>(slice + row * RS + ch * 16);
+        if (m < p.M && n < p.N) {
+          if (have_r) v += r;
+          else if (Rf) v += *reinterpret_cast<const f32x4_t*>(Rf + out_row(m) * p.ldr + n);
+          if (p.act == ACT_QUICK_GELU) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = quick_gelu_f(v[r]);
+          } else if (p.act == ACT_SILU) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = silu_f(v[r]);
+          }
+          if (p.out_f32 == 2) {   // hi|lo: [bf16(v) | bf16(v - bf16(v))] at columns n and N + n of a bf16 [M][2N] matrix
+            bf16_t* Ch = (bf16_t*)p.C + (size_t)batch * p.sC + out_row(m) * p.ldc + n;
+            float hi[4], lo[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { hi[r] = bf2f(f2bf(v[r])); lo[r] = v[r] - hi[r]; }
+            store_n<bf16_t, 4>(Ch, hi);
+            store_n<bf16_t, 4>(Ch + p.N, lo);
+          } else {
+            *reinterpret_cast<f32x4_t*>(C + out_row(m) * p.ldc + n) = v;
+          }
+          if (do_stats || LNF) *reinterpret_cast<f32x4_t*>(slice + row * RS + ch * 16) = v;
+        }
+      };
+      if constexpr (RPRE) {
+#pragma unroll
+        for (int it = 0; it < E_IT; ++it) finish(lane + it * 64, rpre[ps * E_IT + it], true);
+      } else {
+        for (int idx = lane; idx < IP * 16 * CPR; idx += 64) finish(idx, (f32x4_t){0.f, 0.f, 0.f, 0.f}, false);
+      }
+      __builtin_amdgcn_wave_barrier();
+      if (do_stats) {
+        const int row0 = mw + ps * IP * 16;
+        const int nrow = min(IP * 16, p.M - row0);          // rows of this pass inside the matrix
+#pragma unroll
+        for (int k = 0; k < NCR; ++k) {
+          const int c = lane + 64 * k;
+          if (c < WTN && nw + c < p.N) {
+            for (int row = 0; row < nrow; ++row) {
+              const float x = *reinterpret_cast<const float*>(slice + row * RS + c * 4);
+              cs[k] += x; cq[k] = __builtin_fmaf(x, x, cq[k]);
+            }
+          }
+        }
+        if (((ps + 1) * IP * 16) % 64 == 0 || ps == TM / IP - 1) {   // a 64-row block is complete
+          const int rb = row0 / 64;
+#pragma unroll
+          for (int k = 0; k < NCR; ++k) {
+            const int c = lane + 64 * k;
+            if (c < WTN && nw + c < p.N && rb * 64 < p.M) {
+              float* dst = p.colstats + ((size_t)rb * p.N + nw + c) * 2;
+              dst[0] = cs[k]; dst[1] = cq[k];
+            }
+            cs[k] = 0.f; cq[k] = 0.f;
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+      if constexpr (LNF) {
+        // LayerNorm of the pass's finished rows (their f32 values sit in the slices of the WGN waves that share a row band).
+        // Same lane map, summation order and arithmetic as layernorm_kernel<float, bf16, 16> (norm.hip): 16 lanes per row,
+        // lane `sub` owns the 4-column vectors sub, sub + 16, ... of the row.
+        static_assert(BN % 64 == 0 && WTN % 4 == 0, "fused LayerNorm: 16 lanes x 4 columns per sweep");
+        __syncthreads();
+        constexpr int SLICE = IP * 16 * RS, NV = BN / 64;          // NV vectors of 4 columns per lane
+        constexpr int PROWS = WGM * IP * 16;                       // rows of this pass in the workgroup
+        const int sub = lane & 15;
+        bf16_t* __restrict__ Y = (bf16_t*)p.ln_out;
+        for (int rr = wave * 4 + (lane >> 4); rr < PROWS; rr += NW * 4) {
+          const int band = rr / (IP * 16), rl = rr - band * (IP * 16);
+          const int m = m0 + band * WTM + ps * IP * 16 + rl;
+          f32x4_t xv[NV];
+          float sum = 0.f;
+#pragma unroll
+          for (int i = 0; i < NV; ++i) {
+            const int col = (sub + 16 * i) * 4, wq = col / WTN, c = col - wq * WTN;
+            xv[i] = *reinterpret_cast<const f32x4_t*>(smem + (band * WGN + wq) * SLICE + rl * RS + c * 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sum += xv[i][j];
+          }
+#pragma unroll
+          for (int o = 8; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+          const float mean = sum / (float)BN;
+          float sq = 0.f;
+#pragma unroll
+          for (int i = 0; i < NV; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const float d = xv[i][j] - mean; sq += d * d; }
+#pragma unroll
+          for (int o = 8; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
+          const float rstd = 1.0f / sqrtf(sq / (float)BN + p.ln_eps);
+          if (m < p.M) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+              const int col = (sub + 16 * i) * 4;
+              const f32x4_t gm = *reinterpret_cast<const f32x4_t*>(p.ln_gamma + n0 + col);
+              const f32x4_t bt = *reinterpret_cast<const f32x4_t*>(p.ln_beta + n0 + col);
+              float o[4];
+#pragma unroll
+              for (int j = 0; j < 4; ++j) o[j] = (xv[i][j] - mean) * rstd * gm[j] + bt[j];
+              store_n<bf16_t, 4>(Y + (size_t)m * p.N + n0 + col, o);
+            }
+          }
+        }
+        __syncthreads();
+      }
+    }
+  } else if constexpr (EPI == 0) {
+    constexpr int RS = WTN * 2 + 16;
+    constexpr int IPMAX = (STAGES * STAGE / NW) / (16 * RS);
+    constexpr int IP = IPMAX >= TM ? TM : (IPMAX >= TM / 2 && TM % 2 == 0) ? TM / 2 : (IPMAX >= TM / 4 && TM % 4 == 0) ? TM / 4 : 1;
+    static_assert(IPMAX >= 1, "epilogue staging does not fit");
+    constexpr int CPR = WTN / 8;
+    static_assert(WTM % 64 != 0 || 64 % (IP * 16) == 0, "column statistics: an epilogue pass must not span two 64-row blocks");
+    char* const slice = smem + wave * (IP * 16 * RS);
+    const bf16_t* __restrict__ R = p.R ? (const bf16_t*)p.R + (size_t)batch * p.sR : nullptr;
+    bf16_t* __restrict__ C = (bf16_t*)p.C + (size_t)batch * p.sC;
+    // column statistics (GemmArgs::colstats) of the ROUNDED values, as a GroupNorm reading the bf16 tensor would see them:
+    // a lane sums one pair of adjacent columns over the pass's rows
+    const bool do_stats = p.colstats != nullptr;
+    constexpr int NCP = (WTN / 2 + 63) / 64;               // column-pair rounds per lane
+    float cs[NCP][2], cq[NCP][2];
+#pragma unroll
+    for (int k = 0; k < NCP; ++k) { cs[k][0] = cs[k][1] = 0.f; cq[k][0] = cq[k][1] = 0.f; }
+#pragma unroll
+    for (int ps = 0; ps < TM / IP; ++ps) {
+#pragma unroll
+      for (int ii = 0; ii < IP; ++ii) {
+        const int m = mw + (ps * IP + ii) * 16 + r16;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          f32x4_t v = acc[j][ps * IP + ii];
+          const int n = nw + j * 16 + q4 * 4;
+          if (bias && n < p.N) v += *reinterpret_cast<const f32x4_t*>(bias + n);
+          if (R && m < p.M && n < p.N) {   // (bf16 residual trunks are the rare case: added before rounding)
+            const u32x2_t rv = *reinterpret_cast<const u32x2_t*>(R + out_row(m) * p.ldr + n);
+            v[0] += __builtin_bit_cast(float, rv[0] << 16); v[1] += __builtin_bit_cast(float, rv[0] & 0xffff0000u);
+            v[2] += __builtin_bit_cast(float, rv[1] << 16); v[3] += __builtin_bit_cast(float, rv[1] & 0xffff0000u);
+          }
+          if (p.act == ACT_QUICK_GELU) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = quick_gelu_f(v[r]);
+          } else if (p.act == ACT_SILU) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = silu_f(v[r]);
+          }
+          const u32x2_t o = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+          *reinterpret_cast<u32x2_t*>(slice + (ii * 16 + r16) * RS + (j * 16 + q4 * 4) * 2) = o;
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      for (int idx = lane; idx < IP * 16 * CPR; idx += 64) {
+        const int row = idx / CPR, ch = idx - row * CPR;
+        const int m = mw + ps * IP * 16 + row, n = nw + ch * 8;
+        const u32x4_t v = *reinterpret_cast<const u32x4_t*>(slice + row * RS + ch * 16);
+        if (m < p.M && n < p.N) *reinterpret_cast<u32x4_t*>(C + out_row(m) * p.ldc + n) = v;
+      }
+      if (do_stats) {
+        const int row0 = mw + ps * IP * 16;
+        const int nrow = min(IP * 16, p.M - row0);
+#pragma unroll
+        for (int k = 0; k < NCP; ++k) {
+          const int c = 2 * (lane + 64 * k);                 // this lane's column pair
+          if (c < WTN && nw + c < p.N) {
+            for (int row = 0; row < nrow; ++row) {
+              const unsigned u = *reinterpret_cast<const unsigned*>(slice + row * RS + c * 2);
+              const float x0 = __builtin_bit_cast(float, u << 16), x1 = __builtin_bit_cast(float, u & 0xffff0000u);
+              cs[k][0] += x0; cq[k][0] = __builtin_fmaf(x0, x0, cq[k][0]);
+              cs[k][1] += x1; cq[k][1] = __builtin_fmaf(x1, x1, cq[k][1]);
+            }
+          }
+        }
+        if (((ps + 1) * IP * 16) % 64 == 0 || ps == TM / IP - 1) {
+          const int rb = row0 / 64;
+#pragma unroll
+          for (int k = 0; k < NCP; ++k) {
+            const int c = 2 * (lane + 64 * k);
+            if (c < WTN && nw + c < p.N && rb * 64 < p.M)
+              *reinterpret_cast<f32x4_t*>(p.colstats + ((size_t)rb * p.N + nw + c) * 2) = (f32x4_t){cs[k][0], cq[k][0], cs[k][1], cq[k][1]};
+            cs[k][0] = cs[k][1] = 0.f; cq[k][0] = cq[k][1] = 0.f;
+          }
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+}
+

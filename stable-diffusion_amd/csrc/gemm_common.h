@@ -33,6 +33,12 @@ struct GemmArgs {
   // batched, 4-wave register-staged kernels) and sets colstats_done = 1 when the kernel writes them.
   float* colstats;
   int colstats_done;
+  // LayerNorm of the stored rows, fused into the epilogue (gemm2_kernel.h EPI 3; null = off): ln_out [M][N] bf16 =
+  // LayerNorm(C row) * ln_gamma + ln_beta.  Only for launches whose N-tile holds whole rows (N == 320 on the 128x320 tile).
+  void* ln_out;
+  const float* ln_gamma;
+  const float* ln_beta;
+  float ln_eps;
   int debug;   // timing experiments only (sdamd_set_gemm_impl(impl | debug << 8)): 1 = skip the DMA, 2 = skip the MFMAs
 };
 
@@ -59,6 +65,9 @@ template <> struct Cvt<f32e_t> {   // (only reached for f32 outputs: the bf16-ou
 // family fits the problem (the caller then uses the 4-wave register-staged kernels), 0 on launch.
 int launch_gemm2(GemmArgs& a, int dtype, int batch, bool conv, int mode, hipStream_t st);   // mode: g_gemm_impl
 int gemm2_choose_tile(int M, int N, int K, int batch, int mode, size_t ws_bytes, int* splits, int bke, int* stages = nullptr);
+
+// gemm3.hip: the ping-pong instantiations (bf16, 256-row tiles); tile = 256256 | 256320; -1 = not taken
+int launch_gemm2pp(GemmArgs& a, int tile, int batch, bool conv, hipStream_t st);
 
 // out = act(sum_s ws[s] + bias + residual) for a split-K launch (gemm2.hip)
 int launch_splitk_reduce(const GemmArgs& a, hipStream_t st);

@@ -414,7 +414,15 @@ int g_gemm_debug = 0;
 // split3_bf16: f32-rounding-level accuracy at ~2.7x the matrix rate of v_mfma_f32_16x16x4_f32), 0 = exact f32 MFMA.
 int g_f32_emu = 1;
 extern "C" int sdamd_set_f32_mode(int mode) { int old = g_f32_emu; if (mode == 0 || mode == 1) g_f32_emu = mode; return old; }
-extern "C" int sdamd_set_gemm_impl(int impl) { int old = g_gemm_impl; g_gemm_impl = impl & 255; g_gemm_debug = impl >> 8; return old; }
+// Ping-pong kernels (gemm3.hip) for the 256x256 launches (GeGLU GEMMs, VAE / CLIP widths): bit 0 = on (default),
+// bit 2 = the variant that re-reads the B0 fragments.  sdamd_set_gemm_impl carries `g_gemm_pp ^ 1` in bits 20-23, so an
+// impl word without those bits (every existing caller) keeps the default and bit 20 switches the kernels OFF (A/B runs).
+int g_gemm_pp = 1;
+extern "C" int sdamd_set_gemm_impl(int impl) {
+  int old = g_gemm_impl | (g_gemm_debug << 8) | ((g_gemm_pp ^ 1) << 20);
+  g_gemm_impl = impl & 255; g_gemm_debug = (impl >> 8) & 0xfff; g_gemm_pp = ((impl >> 20) & 15) ^ 1;
+  return old;
+}
 
 // Weights of an f32 GEMM / conv3x3, split once into the three bf16 terms of the bf16x3 mode (common.h split3_pair):
 // planes[row][k/32][hi|mid|lo][32], the 32 k of a K-tile stored in the order the MFMA fragments of the f32 activation
@@ -509,6 +517,29 @@ extern "C" int sdamd_gemm(const void* A, const void* W, void* C, const float* bi
   if (dtype == SDAMD_BF16) return pick_tile<bf16_t, false>(a, batch, st);
   if (g_f32_emu) return pick_tile<f32e_t, false>(a, batch, st);
   return pick_tile<float, false>(a, batch, st);
+}
+
+// out [M][N] f32 = A [M][K] W[N][K]^T + bias (+ residual f32), and ln_out [M][N] bf16 = LayerNorm(out row) * gamma + beta
+// from the same launch (gemm2_kernel.h EPI 3).  bf16 operands, N == 320 (the 128x320 tile holds whole rows).
+extern "C" int sdamd_gemm_ln(const void* A, const void* W, float* out, const float* bias, const float* residual, void* ln_out,
+                             const float* ln_gamma, const float* ln_beta, float ln_eps, int M, int N, int K, int lda,
+                             void* stream) {
+  SD_CHECK(N == 320, "gemm_ln: N=%d (the fused LayerNorm needs whole rows in one 320-wide tile)", N);
+  SD_CHECK(ln_out && ln_gamma && ln_beta && out, "gemm_ln: null pointer");
+  SD_CHECK(((uintptr_t)ln_out % 16) == 0 && ((uintptr_t)ln_gamma % 16) == 0 && ((uintptr_t)ln_beta % 16) == 0, "gemm_ln: alignment");
+  GemmArgs a = {};
+  a.splits = 1; a.debug = g_gemm_debug;
+  a.A = A; a.W = W; a.C = out; a.bias = bias; a.R = residual;
+  a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldw = K; a.ldc = N; a.ldr = N;
+  a.act = ACT_NONE; a.out_f32 = 1;
+  a.ln_out = ln_out; a.ln_gamma = ln_gamma; a.ln_beta = ln_beta; a.ln_eps = ln_eps;
+  if (int e = check_common(a, SDAMD_BF16, "gemm_ln")) return e;
+  SD_CHECK((lda * 2) % 16 == 0 && lda >= K, "gemm_ln: lda=%d", lda);
+  SD_CHECK(!residual || ((uintptr_t)residual % 16) == 0, "gemm_ln: residual alignment");
+  SD_CHECK(g_gemm_impl != 1, "gemm_ln: needs the LDS-DMA kernels");
+  const int r = launch_gemm2(a, SDAMD_BF16, 1, false, g_gemm_impl, (hipStream_t)stream);
+  SD_CHECK(r >= 0, "gemm_ln: no kernel takes M=%d N=%d K=%d", M, N, K);
+  return r;
 }
 
 // conv3x3 over NHWC.  pad_mode 0: symmetric pad 1 (diffusion.py / decoder.py convs);

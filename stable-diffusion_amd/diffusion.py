@@ -95,11 +95,18 @@ class UNET_AttentionBlock(engine.HipModule):
         stream ``t`` is a trunk too (three residual adds accumulate into it)."""
         B, H, W, C = x.shape
         dt, td = self.compute_dtype, x.dtype
-        t = engine.conv1x1(engine.groupnorm(x, self.groupnorm, silu=False, out_dtype=dt), self.conv_input,
-                           out_dtype=td).view(B, H * W, C)
-        t = engine.self_attention(engine.layernorm(t, self.layernorm_1, dt), self.attention_1, residual=t)
-        t = engine.cross_attention(engine.layernorm(t, self.layernorm_2, dt), self.attention_2, kv, residual=t)
-        g = engine.linear_geglu(engine.layernorm(t, self.layernorm_3, dt), self.linear_geglu_1)
+        h = engine.groupnorm(x, self.groupnorm, silu=False, out_dtype=dt).view(B, H * W, C)
+        if dt == torch.bfloat16 and td == torch.float32:
+            # every producer of the token trunk also emits the LayerNorm of what it stored (one launch at C = 320)
+            t, n = engine.conv1x1_ln(h, self.conv_input, self.layernorm_1)
+            t, n = engine.self_attention(n, self.attention_1, residual=t, then_ln=self.layernorm_2)
+            t, n = engine.cross_attention(n, self.attention_2, kv, residual=t, then_ln=self.layernorm_3)
+        else:
+            t = engine.conv1x1(h, self.conv_input, out_dtype=td)
+            t = engine.self_attention(engine.layernorm(t, self.layernorm_1, dt), self.attention_1, residual=t)
+            t = engine.cross_attention(engine.layernorm(t, self.layernorm_2, dt), self.attention_2, kv, residual=t)
+            n = engine.layernorm(t, self.layernorm_3, dt)
+        g = engine.linear_geglu(n, self.linear_geglu_1)
         ts = engine.linear_hilo(g, self.linear_geglu_2, t) if dt == torch.bfloat16 else None
         if ts is not None:   # t is only ever read as conv_output's hi|lo operand: the GEMM epilogue writes that form
             return engine.conv1x1_presplit(ts.view(B, H, W, 2 * C), self.conv_output, x, want_stats=True)
@@ -117,17 +124,30 @@ class UNET_AttentionBlock(engine.HipModule):
         B, H, W, C = x.shape
         dt, td = self.compute_dtype, x.dtype
         a2 = self.attention_2
-        t = engine.conv1x1(engine.groupnorm(x, self.groupnorm, silu=False, out_dtype=dt), self.conv_input,
-                           out_dtype=td).view(B, H * W, C)
-        t = engine.self_attention(engine.layernorm(t, self.layernorm_1, dt), self.attention_1, residual=t)
-        q = engine.linear(engine.layernorm(t, self.layernorm_2, dt), a2.q_proj)
+        h = engine.groupnorm(x, self.groupnorm, silu=False, out_dtype=dt).view(B, H * W, C)
+        fused_ln = dt == torch.bfloat16 and td == torch.float32 and ops.gemm_ln_fused(B * H * W, C, dt)
+        if fused_ln:
+            t, n = engine.conv1x1_ln(h, self.conv_input, self.layernorm_1)
+            t, n = engine.self_attention(n, self.attention_1, residual=t, then_ln=self.layernorm_2)
+        else:
+            t = engine.conv1x1(h, self.conv_input, out_dtype=td)
+            t = engine.self_attention(engine.layernorm(t, self.layernorm_1, dt), self.attention_1, residual=t)
+            n = engine.layernorm(t, self.layernorm_2, dt)
+        q = engine.linear(n, a2.q_proj)
         o = torch.empty((2 * B, H * W, C), dtype=q.dtype, device=q.device)
         t2 = torch.empty((2 * B, H * W, C), dtype=td, device=q.device)
+        n3 = torch.empty((2 * B, H * W, C), dtype=dt, device=q.device) if fused_ln else None
         for half in range(2):
-            kvh = kv[half * B:(half + 1) * B]
-            ops.attention(q, kvh[..., :C], kvh[..., C:], a2.n_heads, False, out=o[half * B:(half + 1) * B])
-            engine.linear(o[half * B:(half + 1) * B], a2.out_proj, t, out=t2[half * B:(half + 1) * B])
-        g = engine.linear_geglu(engine.layernorm(t2, self.layernorm_3, dt), self.linear_geglu_1)
+            sl = slice(half * B, (half + 1) * B)
+            kvh = kv[sl]
+            ops.attention(q, kvh[..., :C], kvh[..., C:], a2.n_heads, False, out=o[sl])
+            if fused_ln:
+                engine.linear_ln(o[sl], a2.out_proj, t, self.layernorm_3, out=t2[sl], ln_out=n3[sl])
+            else:
+                engine.linear(o[sl], a2.out_proj, t, out=t2[sl])
+        if not fused_ln:
+            n3 = engine.layernorm(t2, self.layernorm_3, dt)
+        g = engine.linear_geglu(n3, self.linear_geglu_1)
         ts = engine.linear_hilo(g, self.linear_geglu_2, t2) if dt == torch.bfloat16 else None
         out = torch.empty((2 * B, H, W, C), dtype=td, device=q.device)
         if ts is None:

@@ -117,6 +117,26 @@ def linear(x, lin, residual=None, act=ops.ACT_NONE, out_dtype=None, out=None):
     return ops.gemm(x, linear_w(lin, x.dtype), bias_of(lin), residual, act, _out_f32(x, residual, out_dtype), out=out)
 
 
+def linear_ln(x, lin, residual, ln, out=None, ln_out=None):
+    """(t, n) = (linear(x) + residual in f32, LayerNorm(t) as the bf16 operand of the next projection): one launch where
+    ops.gemm_ln_fused says so, else the GEMM followed by the LayerNorm kernel (``ln_out`` only with the fused form)."""
+    M = x.numel() // x.shape[-1]
+    if x.dtype == torch.bfloat16 and ops.gemm_ln_fused(M, lin.out_features, x.dtype):
+        return ops.gemm_ln(x, linear_w(lin, x.dtype), bias_of(lin), residual, f32(ln.weight), f32(ln.bias), ln.eps, out=out, ln_out=ln_out)
+    assert ln_out is None
+    t = ops.gemm(x, linear_w(lin, x.dtype), bias_of(lin), residual, ops.ACT_NONE, _out_f32(x, residual, torch.float32), out=out)
+    return t, layernorm(t, ln, x.dtype)
+
+
+def conv1x1_ln(x, conv, ln):
+    """conv1x1 (bf16 operand -> f32 trunk) + LayerNorm of the result, as linear_ln."""
+    M = x.numel() // x.shape[-1]
+    if x.dtype == torch.bfloat16 and ops.gemm_ln_fused(M, conv.out_channels, x.dtype):
+        return ops.gemm_ln(x, conv1x1_w(conv, x.dtype), bias_of(conv), None, f32(ln.weight), f32(ln.bias), ln.eps)
+    t = conv1x1(x, conv, out_dtype=torch.float32)
+    return t, layernorm(t, ln, x.dtype)
+
+
 def linear_geglu(x, lin):
     """diffusion.py:127-130: x, gate = linear_geglu_1(x).chunk(2, -1); x * gelu(gate) -- as one GEMM
     whose epilogue gates the f32 accumulators when the kernel family supports it (bf16), else the
@@ -218,13 +238,15 @@ def layernorm(x, ln, out_dtype=None):
     return ops.layernorm(x, f32(ln.weight), f32(ln.bias), ln.eps, out_dtype)
 
 
-def self_attention(x, attn, causal=False, residual=None):
+def self_attention(x, attn, causal=False, residual=None, then_ln=None):
     """attention.py:25-75 on token-major x [B,S,C]: fused QKV GEMM -> flash attention -> out-proj GEMM
-    (+ residual, whose dtype the result takes)."""
+    (+ residual, whose dtype the result takes).  ``then_ln``: also return the LayerNorm of the result (linear_ln)."""
     qkv = linear(x, attn.in_proj)
     C = x.shape[-1]
     q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
     o = ops.attention(q, k, v, attn.n_heads, causal)   # one flash kernel family, the VAE's 512-wide head included
+    if then_ln is not None:
+        return linear_ln(o, attn.out_proj, residual, then_ln)
     return linear(o, attn.out_proj, residual)
 
 
@@ -240,9 +262,11 @@ def cross_kv(ctx, attn):
     return ops.gemm(ctx, w, b)
 
 
-def cross_attention(x, attn, kv, residual=None):
-    """attention.py:90-133 with precomputed ``kv`` = cross_kv(context, attn)."""
+def cross_attention(x, attn, kv, residual=None, then_ln=None):
+    """attention.py:90-133 with precomputed ``kv`` = cross_kv(context, attn).  ``then_ln`` as for self_attention."""
     C = x.shape[-1]
     q = linear(x, attn.q_proj)
     o = ops.attention(q, kv[..., :C], kv[..., C:], attn.n_heads, False)
+    if then_ln is not None:
+        return linear_ln(o, attn.out_proj, residual, then_ln)
     return linear(o, attn.out_proj, residual)

@@ -470,6 +470,42 @@ def gemm(a, w, bias=None, residual=None, act=ACT_NONE, out_f32=False, out_hilo=F
     return out
 
 
+FUSE_LAYERNORM = True          # tests / A-B switch: False keeps GEMM and LayerNorm separate launches
+GEMM_LN_MIN_ROWS = 32768       # below this the 128x320 tile leaves most CUs idle (M / 128 workgroups) and two launches are no slower
+
+
+def gemm_ln_fused(M, N, dtype):
+    """True when ``gemm_ln`` runs as ONE launch (sdamd_gemm_ln): bf16 operands, 320-wide rows, enough rows to fill the chip."""
+    return FUSE_LAYERNORM and dtype == torch.bfloat16 and N == 320 and M >= GEMM_LN_MIN_ROWS and gemm_supports_act(ACT_GEGLU, dtype, 256)
+
+
+def gemm_ln(a, w, bias, residual, gamma, beta, eps, out=None, ln_out=None):
+    """(t, n): t [..., N] f32 = a @ w^T + bias (+ residual f32), n [..., N] bf16 = LayerNorm(t) * gamma + beta -- one launch
+    whose epilogue normalises the rows it just stored (N == 320 on the 128x320 tile), instead of a LayerNorm launch that
+    reads the f32 trunk back (diffusion.py:99-100, 110-117, 119-126).  Callers check ``gemm_ln_fused`` first."""
+    _dev(a, w, bias, residual, gamma, beta)
+    K, N = a.shape[-1], w.shape[0]
+    assert a.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and w.shape[1] == K and w.is_contiguous() and a.is_contiguous()
+    lead = a.shape[:-1]
+    M = a.numel() // K
+    assert gamma.dtype == torch.float32 and beta.dtype == torch.float32 and gamma.numel() == N and beta.numel() == N
+    assert bias is None or (bias.dtype == torch.float32 and bias.numel() == N)
+    if out is None:
+        out = torch.empty(lead + (N,), dtype=torch.float32, device=a.device)
+    if ln_out is None:
+        ln_out = torch.empty(lead + (N,), dtype=torch.bfloat16, device=a.device)
+    assert out.dtype == torch.float32 and out.is_contiguous() and out.numel() == M * N
+    assert ln_out.dtype == torch.bfloat16 and ln_out.is_contiguous() and ln_out.numel() == M * N
+    if residual is not None:
+        assert residual.dtype == torch.float32 and residual.is_contiguous() and residual.numel() == M * N
+    nbytes = (M * K + N * K) * 2 + M * N * (4 + 2) + (0 if residual is None else M * N * 4)
+    _timed("gemm_bf16_128x320_ln", 2.0 * M * N * K,
+           lambda: _lib.check(_lib.lib().sdamd_gemm_ln(_p(a), _p(w), _p(out), _p(bias), _p(residual), _p(ln_out), _p(gamma), _p(beta),
+                                                       float(eps), M, N, K, K, _stream())),
+           f"M{M} N{N} K{K}{' +res' if residual is not None else ''} f32out +ln", nbytes)
+    return out, ln_out
+
+
 def _stats_request(want, M, N, device):
     """(stats buffer, ctypes flag) for a launch that should leave GroupNorm column statistics, or (None, None)."""
     if not want or not USE_PRODUCER_STATS or M * N < PRODUCER_STATS_MIN_ELEMS:

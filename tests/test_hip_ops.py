@@ -350,6 +350,31 @@ def test_gemm_fused_geglu(M, C):
     assert rel_l2(got.float().cpu(), want) <= rel_l2(unfused.float().cpu(), want) * 1.05
 
 
+@pytest.mark.parametrize("M,res", [(32768, True), (32768, False), (65536 + 72, True)])
+def test_gemm_with_fused_layernorm(M, res):
+    """sdamd_gemm_ln (diffusion.py:110-117: out_proj + residue, then layernorm of the sum): the f32 result equals
+    sdamd_gemm's bit for bit, the bf16 LayerNorm output equals sdamd_layernorm of that result (same lane map and
+    arithmetic: at most the last bf16 bit where the compiler contracted differently), and both sit within the bf16
+    budget of float64."""
+    K = N = 320
+    a = q(rnd(f"gln.a.{M}", (M, K)), torch.bfloat16).bfloat16().to(DEV)
+    w = q(rnd("gln.w", (N, K), K ** -0.5), torch.bfloat16).bfloat16().to(DEV)
+    b = rnd("gln.b", (N,)).to(DEV)
+    r = (rnd(f"gln.r.{M}", (M, N), 2.0) + 0.5).to(DEV) if res else None
+    gamma, beta = (1.0 + 0.1 * rnd("gln.g", (N,))).to(DEV), (0.1 * rnd("gln.be", (N,))).to(DEV)
+    assert ops.gemm_ln_fused(M, N, torch.bfloat16)
+    t, n = ops.gemm_ln(a, w, b, r, gamma, beta, 1e-5)
+    t2 = ops.gemm(a, w, b, r, out_f32=True)
+    n2 = ops.layernorm(t2, gamma, beta, 1e-5, torch.bfloat16)
+    assert torch.equal(t, t2)
+    d = (n.float() - n2.float()).abs()
+    assert float((d > 0).float().mean()) < 1e-3 and float((d / n2.float().abs().clamp_min(1e-3)).max()) < 2 ** -7, float(d.max())
+    rows = slice(M - 200, M)
+    want_t = a[rows].double().cpu() @ w.double().cpu().t() + b.double().cpu() + (r[rows].double().cpu() if res else 0)
+    want_n = torch.nn.functional.layer_norm(want_t, (N,), gamma.double().cpu(), beta.double().cpu(), 1e-5)
+    assert rel_l2(t[rows].cpu(), want_t) < 1e-5 and rel_l2(n[rows].float().cpu(), want_n) < 4e-3
+
+
 def _bmm_nt(a, b):
     """sdamd_gemm's batched form straight through the C ABI: a [Bt, M, K] @ b [Bt, N, K]^T -> f32 [Bt, M, N] (both
     K-contiguous strided row views; no model uses it since the VAE head has a flash kernel, the ABI keeps it)."""
