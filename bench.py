@@ -324,6 +324,12 @@ def run(args):
     models, cpu_sd = build_models(device, dtype, keep_cpu=(rank == 0 and world == 1 and not args.skip_cpu_baseline),
                                   with_encoder=cfg["img2img"])
 
+    if os.environ.get("SDAMD_DUMP_MAPS"):   # profiling runs: which module every PC of this process belongs to (all libraries are loaded by now)
+        try:
+            with open("/proc/self/maps") as src, open(os.path.join(os.environ["SDAMD_DUMP_MAPS"], f"maps_{os.getpid()}.txt"), "w") as dst:
+                dst.write(src.read())
+        except OSError:
+            pass
     call = GenerateCall(models, cfg, first, batch, args.denoise_steps, device)
     for _ in range(max(1, args.warmup)):           # (the first call captures the graphs: at least one untimed call)
         call()
