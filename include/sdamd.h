@@ -136,6 +136,14 @@ int sdamd_vae_post_quant(const float* x, float* y, const float* w, const float* 
 int sdamd_vae_sample(const float* x, const float* noise, float* out, const float* w, const float* b,
                      int B, int HW, void* stream);
 
+/* Deterministic launch plans (no counterpart in the reference, whose pipeline is batch 1: pipeline.py:93; this is the
+ * shard-invariance extension of SURVEY.md §4 item 5 / §8e).  n >= 1 = the number of independent samples the rows of the
+ * following launches span (UNet batch, VAE micro-batch ...): tile, split-K factor, kernel family and GroupNorm partial
+ * blocks are then planned from ONE sample's rows, so a sample's result is bit-identical whatever the batch it runs in
+ * (the split-K workspace has to grow with n: pass n times the bytes a single sample's plan needs).  1 = plans follow the
+ * batched problem (default, faster).  Process-wide; returns the previous value. */
+int sdamd_set_plan_samples(int n);
+
 /* ---- MFMA GEMM: nn.Linear / conv1x1 (attention.py:19-20,81-85; diffusion.py:18,54,82-85,
  * 156-157; clip.py:45-46).  C[m][n] = act(sum_k A[m][k]*W[n][k] + bias[n] + residual[m][n]);
  * K % 64 == 0, N % 16 == 0; `batch` independent problems with element strides.  C and the

@@ -42,6 +42,7 @@ SIGNATURES = {
     "sdamd_uint8_to_image": (_i, [_vp, _vp, _i, _i, _vp]),
     "sdamd_vae_post_quant": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
     "sdamd_vae_sample": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
+    "sdamd_set_plan_samples": (_i, [_i]),
     "sdamd_gemm_ln": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _i, _i, _i, _vp]),
     "sdamd_gemm": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _ll, _ll, _ll, _ll, _i, _i, _i, _vp, _sz, _vp, _vp, _vp, _vp]),
     "sdamd_split3_weights": (_i, [_vp, _vp, _ll, _i, _i, _vp]),

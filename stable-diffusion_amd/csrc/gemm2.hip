@@ -127,9 +127,10 @@ int launch_splitk_reduce(const GemmArgs& a, hipStream_t st) {
 int gemm2_choose_tile(int M, int N, int K, int batch, int mode, size_t ws_bytes, int* splits, int bke, int* stages) {
   extern int g_gemm_debug;
   if (stages) *stages = 2;
+  const size_t slab = (size_t)M * N * sizeof(float);     // split-K partials of the real problem
+  M = plan_rows(M);                                      // deterministic plans: size the grid as one sample's rows
   auto blocks = [&](int bm, int bn) { return (long long)((M + bm - 1) / bm) * ((N + bn - 1) / bn) * batch; };
   const int nk = K / bke;
-  const size_t slab = (size_t)M * N * sizeof(float);
   auto max_splits = [&]() { return (batch == 1 && slab > 0) ? (int)(ws_bytes / slab) : 1; };
   *splits = 1;
   if (mode >= 2) {
@@ -215,7 +216,7 @@ static int launch_gemm2_t(GemmArgs& a, int batch, bool conv, int mode, hipStream
       case 128160:
         // (92 KB of LDS: one workgroup per CU.  Only where the launch has no second workgroup per CU to lose:
         //  M 8192 N 960 K 320, 384 workgroups, measured 44.9 us with in-register weight splits, 49.9 us with planes)
-        if ((long long)((a.M + 127) / 128) * ((a.N + 159) / 160) * batch * a.splits > 256) { a.splits = 1; return -1; }
+        if ((long long)((plan_rows(a.M) + 127) / 128) * ((a.N + 159) / 160) * batch * a.splits > 256) { a.splits = 1; return -1; }
         return conv ? launch2<T, 128, 160, 2, 2, 2, true>(a, batch, st) : launch2<T, 128, 160, 2, 2, 2, false>(a, batch, st);
       case 64160: return conv ? launch2<T, 64, 160, 2, 2, 2, true>(a, batch, st) : launch2<T, 64, 160, 2, 2, 2, false>(a, batch, st);
       case 128320: return conv ? launch2<T, 128, 320, 2, 4, 2, true>(a, batch, st) : launch2<T, 128, 320, 2, 4, 2, false>(a, batch, st);

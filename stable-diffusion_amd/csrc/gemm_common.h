@@ -61,6 +61,12 @@ template <> struct Cvt<f32e_t> {   // (only reached for f32 outputs: the bf16-ou
 };
 #endif
 
+// Deterministic launch plans (sdamd_set_plan_samples, include/sdamd.h): when a launch's rows are n independent samples the
+// planners (tile, split-K, kernel family, GroupNorm partial blocks) size the problem as ONE sample's rows, so that a
+// sample's result does not depend on how many others share its batch.  plan_rows(M) = the row count the planners see.
+extern int g_plan_samples;
+static inline int plan_rows(int M) { return (g_plan_samples > 1 && M % g_plan_samples == 0) ? M / g_plan_samples : M; }
+
 // gemm2.hip: 8-wave, LDS-DMA-staged kernels (bf16 and exact-f32 MFMA).  Returns -1 when no tile configuration of that
 // family fits the problem (the caller then uses the 4-wave register-staged kernels), 0 on launch.
 int launch_gemm2(GemmArgs& a, int dtype, int batch, bool conv, int mode, hipStream_t st);   // mode: g_gemm_impl

@@ -397,6 +397,7 @@ static int launch_gemm(GemmArgs& a, int batch, hipStream_t st) {
 // prefer 128x128; drop to smaller tiles when the grid would leave most of the 256 CUs idle or
 // when N wastes a large part of a 128-wide tile.  Returns BM*1000 + BN.
 static int choose_tile(int M, int N, int batch) {
+  M = plan_rows(M);
   auto blocks = [&](int bm, int bn) { return (long long)((M + bm - 1) / bm) * ((N + bn - 1) / bn) * batch; };
   const bool n64 = (N % 128) != 0 && (N % 128) <= 64;  // e.g. N = 320: 5 x 64 exact, 128 wastes 17 %
   if (!n64 && blocks(128, 128) >= 512) return 128128;
@@ -408,6 +409,8 @@ static int choose_tile(int M, int N, int batch) {
 // 0 = auto (8-wave LDS-DMA kernels of gemm2.hip where a tile of that family fits, else the 4-wave
 // kernels of this file), 1 = this file only, 2 = gemm2.hip whenever one of its tiles divides N, however
 // few workgroups that makes, 3 = as 2 with a 3-way K split (parity tests at small sizes).
+int g_plan_samples = 1;
+extern "C" int sdamd_set_plan_samples(int n) { int old = g_plan_samples; if (n >= 1) g_plan_samples = n; return old; }
 static int g_gemm_impl = 0;
 int g_gemm_debug = 0;
 // f32 operands: 1 = products on the bf16 matrix pipe from three-term operand splits (six MFMAs, gemm_common.h
@@ -574,7 +577,7 @@ extern "C" int sdamd_conv3x3(const void* x, const void* w, void* y, const float*
     // Few low-resolution rows (UNet batch 2: 8x8 .. 32x32 maps): four phases of a handful of tiles leave the chip idle
     // and a batched launch cannot split K.  Then each phase is a launch of its own with the planner's K split and the
     // reduce kernel placing the rows (fp32 UNet batch 2: the three upsample convs 1.62 -> ~0.6 ms per step).
-    if (g_gemm_impl != 1 && ws && 4LL * ((a.M + 127) / 128) * ((a.N + 159) / 160) < 256) {   // (256 workgroups fill the chip once: measured, 256 keep the batched launch)
+    if (g_gemm_impl != 1 && ws && 4LL * ((plan_rows(a.M) + 127) / 128) * ((a.N + 159) / 160) < 256) {   // (256 workgroups fill the chip once: measured, 256 keep the batched launch)
       int splits = 1;
       const int tile = gemm2_choose_tile(a.M, a.N, a.K, 1, g_gemm_impl, ws_bytes, &splits, dtype == SDAMD_BF16 ? 64 : 32);
       if (tile && splits > 1) {

@@ -413,7 +413,9 @@ static int groupnorm_impl(const void* x, const void* x2, int C1, void* y, const 
   size_t lds = (size_t)pif * C * 2 * sizeof(double);
   SD_CHECK(lds <= 160 * 1024, "groupnorm: C=%d needs %zu B of LDS", C, lds);
   // stats blocks per image: enough to fill the chip, at most 64 (ws size), >= 1 pixel sweep each
-  int want = (2048 + B - 1) / B;
+  extern int g_plan_samples;     // deterministic plans (gemm_common.h): partial blocks per sample as if the batch were one sample
+  const int Bp = (g_plan_samples > 1 && B % g_plan_samples == 0) ? B / g_plan_samples : B;
+  int want = (2048 + Bp - 1) / Bp;
   int nblk = HW / (pif * 4);
   if (nblk > want) nblk = want;
   if (nblk > 64) nblk = 64;

@@ -223,7 +223,7 @@ def conv3x3_trunk(x, conv, compute_dtype, stride=1, upsample=False):
         return ops.conv3x3(ops.split_hilo(x), w2, bias_of(conv), None, stride, 0, upsample, out_f32=True, flops_cin=conv.in_channels,
                            want_stats=True)
     if upsample and stride == 1 and ops.gemm_supports_act(ops.ACT_GEGLU, torch.bfloat16, 256) and \
-            (conv.out_channels % 160 == 0 or conv.out_channels % 256 == 0) and x.shape[0] * x.shape[1] * x.shape[2] >= 256:
+            (conv.out_channels % 160 == 0 or conv.out_channels % 256 == 0) and ops._plan_rows(x.shape[0] * x.shape[1] * x.shape[2]) >= 256:
         # phase form, as conv3x3 above (below 256 low-resolution rows the f32 planner finds no split that fills the
         # chip and the gathered form on the 4-wave kernels is faster: 0.18 vs 0.81 ms at UNet batch 2, 8x8 -> 16x16)
         return ops.conv3x3(x, conv3x3_up_phase_w(conv, x.dtype, 1), bias_of(conv), None, 1, 0, 2)

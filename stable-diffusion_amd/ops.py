@@ -97,7 +97,36 @@ def _tile_tag(M, N, K, dtype, ws, batch=1, act=0, f32_residual=False, conv=False
 
 
 _gemm_ws = {}
+_gemm_ws_retired = []     # outgrown buffers stay alive: an earlier captured graph may still point at them
 GEMM_WS_BYTES = 64 << 20
+PLAN_SAMPLES = 1          # > 1: deterministic launch plans for batches of that many samples (plan_samples below)
+
+
+class plan_samples:
+    """``with ops.plan_samples(n):`` -- the launches inside span n independent samples and are planned (tile, split-K,
+    kernel family, GroupNorm partial blocks, fusion thresholds) from ONE sample's rows (sdamd_set_plan_samples), so each
+    sample's result is bit-identical to its result in any other batch size run the same way.  n = 0 / None: no change.
+    The split-K workspace grows to n x GEMM_WS_BYTES (same split limits per sample)."""
+
+    def __init__(self, n):
+        self.n = int(n) if n else 0
+
+    def __enter__(self):
+        global PLAN_SAMPLES
+        self.old = PLAN_SAMPLES
+        if self.n >= 1:
+            PLAN_SAMPLES = self.n
+            _lib.lib().sdamd_set_plan_samples(self.n)
+        return self
+
+    def __exit__(self, *exc):
+        global PLAN_SAMPLES
+        PLAN_SAMPLES = self.old
+        _lib.lib().sdamd_set_plan_samples(self.old)
+
+
+def _plan_rows(M):
+    return M // PLAN_SAMPLES if PLAN_SAMPLES > 1 and M % PLAN_SAMPLES == 0 else M
 
 
 def _gemm_workspace(device):
@@ -107,12 +136,17 @@ def _gemm_workspace(device):
     launches that overlap in time on two streams of one device must not share it."""
     key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
     ws = _gemm_ws.get(key)
-    if ws is None:
+    need = GEMM_WS_BYTES * max(1, PLAN_SAMPLES)
+    if ws is None or ws.numel() < need:
         if torch.cuda.is_current_stream_capturing():
-            raise _lib.SdamdError("split-K workspace requested for the first time under graph capture: run the ops once "
+            raise _lib.SdamdError("split-K workspace (re)allocation under graph capture: run the ops once "
                                   "(or ops.ensure_workspaces) before capturing")
-        ws = torch.empty(GEMM_WS_BYTES, dtype=torch.uint8, device=device)
+        if ws is not None:
+            _gemm_ws_retired.append(ws)
+        ws = torch.empty(need, dtype=torch.uint8, device=device)
         _gemm_ws[key] = ws
+    if ws.numel() != need:
+        ws = ws[:need]       # the planner's split limit must not depend on what an earlier, larger request left behind
     return ws
 
 
@@ -412,7 +446,7 @@ def gemm_hilo_fused(M, N, K, dtype):
     """True when sdamd_gemm can emit its result directly as the bf16 hi|lo pair (out_f32 = 2)."""
     if dtype != torch.bfloat16 or not gemm_supports_act(ACT_GEGLU, dtype, 256):    # 4-wave kernels forced
         return False
-    tile = _lib.lib().sdamd_gemm_tile(M, N, K, 1, _code(dtype), GEMM_WS_BYTES, 0) % 1000000
+    tile = _lib.lib().sdamd_gemm_tile(M, N, K, 1, _code(dtype), GEMM_WS_BYTES * max(1, PLAN_SAMPLES), 0) % 1000000
     return tile in (64160, 128160, 128320, 256256, 256320)      # the LDS-DMA tiles (gemm2.hip); the register-staged ones have no such epilogue
 
 
@@ -476,7 +510,7 @@ GEMM_LN_MIN_ROWS = 32768       # below this the 128x320 tile leaves most CUs idl
 
 def gemm_ln_fused(M, N, dtype):
     """True when ``gemm_ln`` runs as ONE launch (sdamd_gemm_ln): bf16 operands, 320-wide rows, enough rows to fill the chip."""
-    return FUSE_LAYERNORM and dtype == torch.bfloat16 and N == 320 and M >= GEMM_LN_MIN_ROWS and gemm_supports_act(ACT_GEGLU, dtype, 256)
+    return FUSE_LAYERNORM and dtype == torch.bfloat16 and N == 320 and _plan_rows(M) >= GEMM_LN_MIN_ROWS and gemm_supports_act(ACT_GEGLU, dtype, 256)
 
 
 def gemm_ln(a, w, bias, residual, gamma, beta, eps, out=None, ln_out=None):
@@ -508,7 +542,7 @@ def gemm_ln(a, w, bias, residual, gamma, beta, eps, out=None, ln_out=None):
 
 def _stats_request(want, M, N, device):
     """(stats buffer, ctypes flag) for a launch that should leave GroupNorm column statistics, or (None, None)."""
-    if not want or not USE_PRODUCER_STATS or M * N < PRODUCER_STATS_MIN_ELEMS:
+    if not want or not USE_PRODUCER_STATS or _plan_rows(M) * N < PRODUCER_STATS_MIN_ELEMS:
         return None, None
     return torch.empty(((M + 63) // 64, N, 2), dtype=torch.float32, device=device), ctypes.byref(ctypes.c_int(0))
 

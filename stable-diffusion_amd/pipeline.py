@@ -11,7 +11,8 @@ Differences a caller can observe (all documented in DESIGN.md):
   * extensions: ``prompt`` may be a list (batch of independent images, image i uses ``seed + i``),
     ``strength_semantics`` selects the img2img schedule slice, ``return_latents`` for tests, ``all_gather=True`` ends
     the call with the one RCCL all-gather of the decoded images over the ranks of a sharded job (every rank passes
-    the same number of prompts),
+    the same number of prompts), ``deterministic_plan=True`` plans every launch from ONE image's rows (ops.plan_samples):
+    image i is then bit-identical whatever batch (or shard of a multi-GPU job) it runs in, at a throughput cost,
     ``preview(step_index, timestep, uint8 images [B,H,W,3])`` restores the per-step decode as a callback.
 """
 import numpy as np
@@ -242,7 +243,7 @@ def _denoise_loop(diffusion, context, timesteps, coef, noise, latents, cfg_scale
     # (a captured graph keeps the f32 mode it was captured under; the guidance scale is NOT in the key: it rides in the
     #  coefficient table the graph reads)
     key = (id(diffusion), diffusion.compute_dtype, tuple(latents.shape), str(latents.device), len(timesteps), bool(do_cfg),
-           noise is None, ops.get_f32_mode())
+           noise is None, ops.get_f32_mode(), ops.PLAN_SAMPLES)
     ent = _LOOP_CACHE.get(key)
     stamp = _weights_stamp(diffusion)
     if ent is not None and ent[0] == stamp and ent[1].rebind(context, timesteps, coef, noise, latents, cfg_scale):
@@ -282,11 +283,13 @@ def encode_prompts(clip, pos_tokens, neg_tokens=None):
     return clip(toks)
 
 
-def decode_to_uint8(decoder, latents, micro_batch=8):
+def decode_to_uint8(decoder, latents, micro_batch=8, deterministic_plan=False):
     """Final VAE decode + rescale/clamp/truncate -> uint8 [B,H,W,3] on the device."""
     outs = []
     for i in range(0, latents.shape[0], micro_batch):
-        outs.append(ops.image_to_uint8(decoder(latents[i:i + micro_batch].contiguous())))
+        chunk = latents[i:i + micro_batch].contiguous()
+        with ops.plan_samples(chunk.shape[0] if deterministic_plan else 0):
+            outs.append(ops.image_to_uint8(decoder(chunk)))
     return outs[0] if len(outs) == 1 else torch.cat(outs)
 
 
@@ -355,7 +358,7 @@ def _draw_step_noise(samplers, timesteps, shape, pending=False):
 
 
 def prepare_latents(seeds, sampler_cls, steps, shape, device, encoder=None, images_u8=None, strength=0.7,
-                    strength_semantics="reference", pending_noise=False):
+                    strength_semantics="reference", pending_noise=False, deterministic_plan=False):
     """Per image: its own CPU generator and the reference's RNG call order:
     txt2img: randn(latents) then one randn per step with t>0; img2img: randn(encoder noise),
     randn(add_noise), then the per-step draws (none for a deterministic sampler: noise is None).
@@ -371,8 +374,11 @@ def prepare_latents(seeds, sampler_cls, steps, shape, device, encoder=None, imag
     if images_u8 is not None:
         enc_noise = torch.stack([sm.draw_noise(shape[1:]) for sm in samplers]).to(device)
         mb = 8      # micro-batch like the decoder: a 512^2 x 128-channel f32 trunk tensor is 134 MB per image
-        latents = torch.cat([encoder(ops.uint8_to_image(images_u8[i:i + mb].contiguous()), enc_noise[i:i + mb].contiguous())
-                             for i in range(0, len(samplers), mb)])
+        chunks = []
+        for i in range(0, len(samplers), mb):
+            with ops.plan_samples(min(mb, len(samplers) - i) if deterministic_plan else 0):
+                chunks.append(encoder(ops.uint8_to_image(images_u8[i:i + mb].contiguous()), enc_noise[i:i + mb].contiguous()))
+        latents = torch.cat(chunks)
         for sm in samplers:
             (sm.set_strength if strength_semantics == "reference" else sm.set_strength_steps)(strength=strength)
         if len(samplers[0].timesteps) == 0:
@@ -414,6 +420,7 @@ def generate(
     trace=None,
     preview=None,
     all_gather=False,
+    deterministic_plan=False,
 ):
     with torch.no_grad():
         if not (0 < strength <= 1):
@@ -444,23 +451,26 @@ def generate(
             images_u8 = torch.from_numpy(arr).to(device).contiguous()
         timesteps, coef, noise, latents = prepare_latents(
             seeds, sampler_cls, steps, shape, device, models.get("encoder") if input_image is not None else None,
-            images_u8, strength, strength_semantics, pending_noise=True)
+            images_u8, strength, strength_semantics, pending_noise=True, deterministic_plan=deterministic_plan)
         # (the step noise is still being drawn on pool threads: tokenising, the CLIP launches and the loop's table refresh
         #  run meanwhile; DenoiseLoop waits for it last)
         pos = _token_tensor(tokenizer, prompts, device)
-        context = encode_prompts(models["clip"], pos, _token_tensor(tokenizer, negs, device) if do_cfg else None)
+        ncopies = 2 if do_cfg else 1
+        with ops.plan_samples(ncopies * B if deterministic_plan else 0):
+            context = encode_prompts(models["clip"], pos, _token_tensor(tokenizer, negs, device) if do_cfg else None)
 
-        loop = _denoise_loop(models["diffusion"], context, timesteps, coef, noise, latents, cfg_scale, do_cfg, use_graph)
-        if preview is None:
-            final = loop.run(trace)
-        else:   # the reference's per-step preview (pipeline.py:156-164) as an opt-in callback
-            for i in range(loop.n_steps):
-                loop.step()
-                if trace is not None:
-                    trace.append(loop.latents.clone())
-                preview(i, int(timesteps[i]), decode_to_uint8(models["decoder"], loop.latents.clone()).cpu().numpy())
-            final = loop.latents
-        images = decode_to_uint8(models["decoder"], final)
+        with ops.plan_samples(ncopies * B if deterministic_plan else 0):
+            loop = _denoise_loop(models["diffusion"], context, timesteps, coef, noise, latents, cfg_scale, do_cfg, use_graph)
+            if preview is None:
+                final = loop.run(trace)
+            else:   # the reference's per-step preview (pipeline.py:156-164) as an opt-in callback
+                for i in range(loop.n_steps):
+                    loop.step()
+                    if trace is not None:
+                        trace.append(loop.latents.clone())
+                    preview(i, int(timesteps[i]), decode_to_uint8(models["decoder"], loop.latents.clone()).cpu().numpy())
+                final = loop.latents
+        images = decode_to_uint8(models["decoder"], final, deterministic_plan=deterministic_plan)
         if all_gather:   # multi-GPU job (distributed.py): this rank's images -> every rank's, rank order, ONE collective
             from . import distributed
             images = distributed.all_gather_images(images)
