@@ -100,6 +100,7 @@ def parse_args():
     ap.add_argument("--skip-roofline", action="store_true")
     ap.add_argument("--skip-fp32-latency", action="store_true")
     ap.add_argument("--skip-predrawn", action="store_true")
+    ap.add_argument("--deterministic-plan", action="store_true", help="generate(deterministic_plan=True): bit-exact shard invariance, slower (rehearsal)")
     return ap.parse_args()
 
 
@@ -278,8 +279,9 @@ def cpu_baseline_leg(cpu_sd):
 class GenerateCall:
     """This rank's share of a BASELINE config as ONE pipeline.generate() call (prompts, seeds, input images fixed)."""
 
-    def __init__(self, models, cfg, first_image, batch, denoise_steps, device):
+    def __init__(self, models, cfg, first_image, batch, denoise_steps, device, deterministic_plan=False):
         self.models, self.cfg, self.B, self.device = models, cfg, batch, device
+        self.det = deterministic_plan
         self.tok = synth.SyntheticTokenizer()
         self.prompts = [f"synthetic:{first_image + i}" for i in range(batch)]
         self.kw = dict(models=models, seed=42 + first_image, device=str(device), sampler="ddpm", steps=denoise_steps,
@@ -292,7 +294,7 @@ class GenerateCall:
                                         for i in range(batch)], strength=0.8, strength_semantics="intended")
 
     def __call__(self, use_graph=True, gather=True):
-        return pipeline.generate(self.prompts, "", use_graph=use_graph, all_gather=gather, **self.kw)
+        return pipeline.generate(self.prompts, "", use_graph=use_graph, all_gather=gather, deterministic_plan=self.det, **self.kw)
 
     def loop(self):
         """The captured DenoiseLoop generate() keeps for this shape (for the UNet step latency)."""
@@ -317,7 +319,7 @@ def run(args):
     else:                                          # weak scaling: every GPU its own images
         batch = cfg["batch"] if args.batch is None else args.batch
         first, total = rank * batch, world * batch
-    standard = args.batch is None and args.denoise_steps == 50
+    standard = args.batch is None and args.denoise_steps == 50 and not args.deterministic_plan
     if cfg["res"] != 512:                          # the reference's resolution is four module constants (pipeline.py:9-13)
         pipeline.WIDTH = pipeline.HEIGHT = cfg["res"]
         pipeline.LATENTS_WIDTH = pipeline.LATENT_HEIGHT = cfg["res"] // 8
@@ -330,7 +332,7 @@ def run(args):
                 dst.write(src.read())
         except OSError:
             pass
-    call = GenerateCall(models, cfg, first, batch, args.denoise_steps, device)
+    call = GenerateCall(models, cfg, first, batch, args.denoise_steps, device, args.deterministic_plan)
     for _ in range(max(1, args.warmup)):           # (the first call captures the graphs: at least one untimed call)
         call()
     torch.cuda.synchronize()

@@ -372,7 +372,7 @@ static int launch_gemm(GemmArgs& a, int batch, hipStream_t st) {
   // 23040 leaves most CUs idle): aim at >= 512 workgroups with up to 16 splits (8 -> 16 on the 8x8-level convs of the
   // fp32 UNet at batch 2: -7...-10 % in situ), keep >= 8 K-tiles per split
   a.splits = 1;
-  const long long blocks = (long long)a.tiles_m * a.tiles_n * batch;
+  const long long blocks = (long long)((plan_rows(a.M) + BM - 1) / BM) * a.tiles_n * batch;   // (deterministic plans: one sample's rows)
   const int nk = a.K / (int)(128 / sizeof(T));
   const size_t slab = (size_t)a.M * a.N * sizeof(float);
   if (batch == 1 && a.ws && blocks < 256 && nk >= 16 && a.ldr % 4 == 0 && a.ldc % 4 == 0) {

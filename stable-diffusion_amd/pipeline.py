@@ -108,7 +108,8 @@ class DenoiseLoop:
         unet = diffusion.unet
         self.kv = unet.prompt_state(context)
         temb = time_embedding_table(timesteps).to(dev)                                # [S,320], bit-exact table
-        self.tb_table = unet.time_bias_table(diffusion.time_embedding(temb))          # [S, sum(Cout)] f32
+        with ops.plan_samples(1):     # (rows = schedule steps, not samples: never planned per sample)
+            self.tb_table = unet.time_bias_table(diffusion.time_embedding(temb))      # [S, sum(Cout)] f32
         self.tb_row = torch.empty(self.tb_table.shape[1], dtype=torch.float32, device=dev)
         self.tb = unet.time_bias_slices(self.tb_row)
         noise = _resolve_noise(noise)
@@ -184,7 +185,8 @@ class DenoiseLoop:
             return False
         self.set_context(context)
         temb = time_embedding_table(timesteps).to(self.latents.device)
-        self.tb_table.copy_(self.diffusion.unet.time_bias_table(self.diffusion.time_embedding(temb)))
+        with ops.plan_samples(1):
+            self.tb_table.copy_(self.diffusion.unet.time_bias_table(self.diffusion.time_embedding(temb)))
         if cfg_scale is not None:
             self.cfg_scale = float(cfg_scale)
         self.coef.copy_(self._coef_with_scale(coef, self.cfg_scale), non_blocking=True)
