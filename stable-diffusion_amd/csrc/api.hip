@@ -15,7 +15,7 @@ int sdamd_set_error(int code, const char* fmt, ...) {
 
 extern "C" const char* sdamd_last_error() { return g_err; }
 
-extern "C" int sdamd_abi_version() { return 6; }
+extern "C" int sdamd_abi_version() { return 7; }
 
 // Number of visible HIP devices, or a negative HIP error code (no GPU / no driver).
 extern "C" int sdamd_device_count() {

@@ -162,6 +162,9 @@ int gemm2_choose_tile(int M, int N, int K, int batch, int mode, size_t ws_bytes,
     const long long b64 = blocks(64, 160);
     if (b160 < 256 && b64 >= 256 && b320 < 256 && nk <= 40) return 64160;
   }
+  // (Round 3 re-measured the 64x160 tile for just the bf16 16x16-level GEMMs -- M 4096, N 1280, K <= 2560, exactly one
+  //  128x160 workgroup per CU: -19...-31 % per launch with rotated operands (experiments/smallgrid.py), -0.03 % per
+  //  captured UNet step: again not kept.)
   if (b320 >= 256) return 128320;
   if (bke == 32) {
     // f32 operands (exact 16x16x4 MFMA, ~4x the issue cycles per byte staged): the 8-wave layout only

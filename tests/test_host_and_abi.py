@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     handle = ctypes.CDLL(_lib.LIB_PATH)
     for name in declared:
         assert hasattr(handle, name), name
-    assert _lib.lib().sdamd_abi_version() == 6
+    assert _lib.lib().sdamd_abi_version() == 7
     # host-side tile choice (no GPU needed): 8-wave LDS-DMA tile for a big f32 GEMM, 4-wave 64x64 for a small one
     assert _lib.lib().sdamd_gemm_tile(65536, 320, 320, 1, 0, 0, 0) == 128320
     assert _lib.lib().sdamd_gemm_tile(512, 1280, 1280, 1, 0, 0, 0) == 64064
