@@ -5,6 +5,10 @@ import bench
 from sd_amd import ops, engine
 torch.set_grad_enabled(False)
 dev = torch.device("cuda", 0)
+import os
+if os.environ.get("SDAMD_IMPL"):   # library switch word for an A/B (sdamd_set_gemm_impl), e.g. 8388608 = halo-staged convs off
+    from sd_amd import _lib
+    _lib.lib().sdamd_set_gemm_impl(int(os.environ["SDAMD_IMPL"]))
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 dtype = torch.bfloat16 if (len(sys.argv) < 3 or sys.argv[2] == "bf16") else torch.float32
 models, _ = bench.build_models(dev, dtype, False)

@@ -47,6 +47,7 @@ SIGNATURES = {
     "sdamd_gemm": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _ll, _ll, _ll, _ll, _i, _i, _i, _vp, _sz, _vp, _vp, _vp, _vp]),
     "sdamd_split3_weights": (_i, [_vp, _vp, _ll, _i, _i, _vp]),
     "sdamd_gemm_tile": (_i, [_i, _i, _i, _i, _i, _sz, _i]),
+    "sdamd_conv3x3_halo": (_i, [_i] * 9 + [_sz]),
     "sdamd_set_gemm_impl": (_i, [_i]),
     "sdamd_set_f32_mode": (_i, [_i]),
     "sdamd_gemm_supports_act": (_i, [_i, _i, _i]),

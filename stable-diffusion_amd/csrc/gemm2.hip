@@ -61,6 +61,10 @@ template <typename T, int BM, int BN, int WGM, int WGN, int STAGES, bool CONV, i
 static int launch2_epi(GemmArgs& a, int batch, hipStream_t st) {
   constexpr int lds = STAGES * (BM * 128 + (std::is_same<T, f32w_t>::value ? BN * 192 : BN * 128));
   static_assert(lds <= 160 * 1024, "gemm2: LDS budget");
+  if constexpr (CONV && std::is_same<T, bf16_t>::value && BM == 128 && BN == 160 && STAGES == 2 && (EPI == 0 || EPI == 1)) {
+    const int r = launch_gemm2halo(a, EPI, batch, st);   // halo-staged form (gemm4.hip) where the geometry allows it
+    if (r >= 0) return r;
+  }
   static std::atomic<unsigned long long> lds_ok{0};
   if (sd_lds_opt_in(lds_ok, (const void*)gemm2_kernel<T, BM, BN, WGM, WGN, STAGES, CONV, EPI>, lds) != hipSuccess)
     return sdamd_set_error(2, "gemm2: cannot reserve %d bytes of LDS", lds);

@@ -32,8 +32,10 @@
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void gbl_void_t;
 
-// 16-byte source for conv taps that fall into the zero padding
-static __device__ __attribute__((aligned(256))) const unsigned int g_zero_page[64] = {0};
+// source for conv taps that fall into the zero padding: 16 bytes per lane for the gathered form; the halo-staged form
+// adds its channel offset to every source alike, so the page spans the largest Cin it takes (HALO_MAX_CIN) + 64 bytes
+#define HALO_MAX_CIN 4096
+static __device__ __attribute__((aligned(256))) const unsigned int g_zero_page[HALO_MAX_CIN / 2 + 64] = {0};
 
 __device__ __forceinline__ int swz2(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
@@ -63,9 +65,13 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
 // (EPI 1 is a kernel of its own because a first build with the prefetch and every other epilogue in one kernel made
 // the launches WITHOUT a residual 6-13 us slower inside a UNet step, where consecutive launches are different
 // kernels, while a back-to-back microbenchmark saw nothing: code executed once per launch is not free.)
-// PP: the "ping-pong" main loop (see GEMM2 PING-PONG below); false = the one-barrier-per-K-tile ring of the header.
+// PP: 0 = the one-barrier-per-K-tile ring of the header; 1, 2 = the "ping-pong" main loop (see GEMM2 PING-PONG below);
+//     3, 4, 5 = the halo-staged conv3x3 loop for images 64, 32, 16 pixels wide (see GEMM2 HALO below).
 template <typename T, int BM, int BN, int WGM, int WGN, int STAGES, bool CONV, int EPI, int PP>
 __device__ __forceinline__ void gemm2_body(const GemmArgs& p) {
+  constexpr bool PPL = PP == 1 || PP == 2;
+  constexpr int HALO_W = PP == 3 ? 64 : PP == 4 ? 32 : PP == 5 ? 16 : 0;
+  constexpr bool HALO = HALO_W != 0;
   constexpr bool F32 = sizeof(T) == 4;     // exact-f32 MFMA (v_mfma_f32_16x16x4_f32) on f32 operands
   // f32 operands split into 3 bf16 terms, 6 bf16 MFMAs (split3_bf16).  WPL: the weight operand arrives split already
   // (GemmArgs::W3, three bf16 planes of 32 k = 64 bytes per row and K-tile), so only the activation fragments are split
@@ -366,7 +372,81 @@ __device__ __forceinline__ void gemm2_body(const GemmArgs& p) {
       (stage_piece(std::integral_constant<int, lo + Q * st>{}, stage, k0, ky, kx), ...);
     }(std::make_integer_sequence<int, (hi - lo + st - 1) / st>{});
   };
-  if constexpr (PP) {
+  // ---- GEMM2 HALO (PP 3 / 4 / 5): conv3x3, stride 1, pad 1, on images HALO_W = 64 / 32 / 16 pixels wide, 4-wave 128-row
+  // tile = BM / HALO_W whole image rows (never across images).  The gathered form stages the tile's 128 input rows once
+  // per filter tap -- 9 x 16 KB per 64 input channels, 45 % of everything the tile stages.  Here the K loop runs
+  // channel-chunk-major: the (rows + 2) x (HALO_W + 2) input halo of a 32-channel chunk is staged ONCE (64 bytes per
+  // pixel, <= 20 KB) and the nine taps are nine address shifts of the activation fragment reads.  A step (one barrier)
+  // is two consecutive (chunk, tap) items, K = 2 x 32: the W tile is 160 rows x [32 channels of item 0 | 32 of item 1],
+  // laid out and read exactly like the 64-deep tile of the gathered form.  Nine steps = 18 items = two chunks = one
+  // "cycle"; the even chunk lives in halo buffer 0, the odd one in buffer 1, so the (buffer, ky, kx) of every fragment
+  // read is a compile-time immediate on top of one per-lane offset per (kx, 16-row block): the halo row pitch is a
+  // multiple of 16 pixels, which keeps the bank swizzle (chunk ^= (pixel >> 2) & 3) invariant under ky.  DMA per step:
+  // the next step's W tile (5 pieces per wave) + the halo pieces of the chunk after next, spread over the four steps
+  // in which its buffer is idle (buffer 1: steps 0-3, buffer 0: steps 5-8; 5 pieces per wave and chunk) -- 6.25 pieces
+  // per wave and step instead of 9.  LDS: W ring 2 x 20 KB + halo 2 x <= 20 KB = 80 KB, two workgroups per CU.
+  // The K order (chunk-major) differs from the gathered form's (tap-major): same products, another f32 summation order.
+  constexpr int H_WD = HALO ? HALO_W : BM;
+  constexpr int H_HP = H_WD + 16, H_HR = BM / H_WD + 2;                  // halo row pitch (pixels) and rows
+  constexpr int H_BYTES = H_HR * H_HP * 64, H_PIECES = H_BYTES / 1024, H_INS = (H_PIECES + NW - 1) / NW;
+  constexpr int H_WST = BN * 128, H_BASE = 2 * H_WST;                    // W ring stage; halo buffers behind the ring
+  [[maybe_unused]] const T* hsrc[H_INS];       // per-lane source of halo piece wave + NW*i at channel 0
+  [[maybe_unused]] const TW* hwsrc[B_INS];     // per-lane source of W piece wave + NW*i at k = 0
+  [[maybe_unused]] int aoff[3][TM];            // activation fragment offset inside a halo buffer, per kx and 16-row block
+  [[maybe_unused]] bool wsel = false;          // this lane's 16-byte chunk of a W row belongs to item 1 of the step
+  [[maybe_unused]] int wpar = 0, hq = 0, hq1 = 0;   // W ring buffer of the current step; current / end cycle
+  [[maybe_unused]] auto h_issue_w = [&](int par, int ka, int kb) {
+    if (GEMM2_DBG(1)) return;
+    const int delta = wsel ? kb : ka;
+#pragma unroll
+    for (int i = 0; i < B_INS; ++i)
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)(hwsrc[i] + delta), (lds_void_t*)(smem + par * H_WST + (wave + NW * i) * 1024), 16, 0, 0);
+  };
+  [[maybe_unused]] auto h_issue_h = [&](auto IC, int hb, int chunk) {
+    constexpr int i = decltype(IC)::value;
+    if (GEMM2_DBG(1)) return;
+    if (H_PIECES % NW != 0 && i == H_INS - 1 && wave + NW * i >= H_PIECES) return;
+    __builtin_amdgcn_global_load_lds((gbl_void_t*)(hsrc[i] + chunk * 32), (lds_void_t*)(smem + H_BASE + hb * H_BYTES + (wave + NW * i) * 1024), 16, 0, 0);
+  };
+  if constexpr (HALO) {
+    static_assert(CONV && !F32 && !EMU && NW == 4 && WGM == 2 && BM == 128 && STAGES == 2 && B_PIECES % NW == 0 && BM % H_WD == 0 && H_WD % 16 == 0,
+                  "halo loop: bf16 conv on the 4-wave 128-row tile");
+    static_assert(H_BYTES % 1024 == 0 && H_INS == 5 && H_BASE + 2 * H_BYTES <= 80 * 1024, "halo loop: piece schedule / LDS budget (two workgroups per CU)");
+    const int hw = p.Ho * p.Wo;
+    const int n_img = m0 / hw, y0 = (m0 - n_img * hw) / HALO_W;
+#pragma unroll
+    for (int i = 0; i < H_INS; ++i) {
+      const int g = min(wave + NW * i, H_PIECES - 1);
+      const int slot = g * 16 + (lane >> 2);                            // pixel slot of the halo buffer
+      const int hy = slot / H_HP, hx = slot - hy * H_HP;
+      const int sc = (lane & 3) ^ ((slot >> 2) & 3);                    // source chunk landing in this lane's position
+      const int y = y0 - 1 + hy, x = hx - 1;
+      const bool in = (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)HALO_W;
+      hsrc[i] = (in ? A + ((long long)(n_img * p.H + y) * HALO_W + x) * p.Cin : reinterpret_cast<const T*>(g_zero_page)) + sc * 8;
+    }
+#pragma unroll
+    for (int i = 0; i < B_INS; ++i) {
+      const int row = (wave + NW * i) * 8 + rr;
+      const int n = min(n0 + row, p.N - 1);
+      hwsrc[i] = W + (size_t)n * p.ldw + ((cl ^ ((row >> 1) & 7)) & 3) * 8;
+    }
+    wsel = ((cl ^ (((wave * 8 + rr) >> 1) & 7)) >> 2) != 0;             // (32 rows further the swizzle repeats: the same for every piece)
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int ml = wm * WTM + i * 16 + (lane & 15);
+      const int yl = ml / HALO_W, xl = ml - yl * HALO_W;
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int hp = yl * H_HP + xl + kx;
+        aoff[kx][i] = hp * 64 + ((((lane >> 4) ^ (hp >> 2)) & 3) << 4);
+      }
+    }
+    const int ncyc = p.Cin / 64;
+    hq = (int)((long long)ncyc * split / p.splits);
+    hq1 = (int)((long long)ncyc * (split + 1) / p.splits);
+    [&]<int... I>(std::integer_sequence<int, I...>) { (h_issue_h(std::integral_constant<int, I>{}, 0, 2 * hq), ...); }(std::make_integer_sequence<int, H_INS>{});
+    h_issue_w(0, hq * 64, p.Cin + hq * 64);
+  } else if constexpr (PPL) {
     static_assert(NW == 8 && WGM == 2 && STAGES == 2 && TM % 2 == 0 && !F32 && !EMU, "ping-pong: 8 waves as 2M x 4N, bf16, 2-stage ring");
     static_assert(A_PIECES % NW == 0 && B_PIECES % NW == 0 && A_INS % 2 == 0 && B_INS >= 2, "ping-pong: uniform DMA piece counts per wave");
     int ky = 0, kx = 0;
@@ -415,7 +495,48 @@ __device__ __forceinline__ void gemm2_body(const GemmArgs& p) {
       for (int k = 0; k < (TM / E_IP) * E_IT; ++k) rpre[k] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     }
   }
-  if constexpr (PP) {
+  if constexpr (HALO) {
+    const int r16h = lane & 15, q4h = lane >> 4;
+    auto h_step = [&](auto JC) {
+      constexpr int J = decltype(JC)::value;
+      const bool more = !(J == 8 && hq + 1 >= hq1);
+      wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();
+      if (more) {   // W tile of the next step
+        constexpr int nj = (J + 1) % 9, ia = 2 * nj, ib = ia + 1;
+        const int kq = (hq + (J == 8 ? 1 : 0)) * 64;
+        h_issue_w(wpar ^ 1, (ia % 9) * p.Cin + kq + (ia >= 9 ? 32 : 0), (ib % 9) * p.Cin + kq + (ib >= 9 ? 32 : 0));
+      }
+      // halo: the odd chunk of this cycle into buffer 1 while steps 0-3 only read buffer 0; the next cycle's even chunk
+      // into buffer 0 once step 4 (its last reader, one barrier ago) is done
+      if constexpr (J == 0) { h_issue_h(std::integral_constant<int, 0>{}, 1, 2 * hq + 1); h_issue_h(std::integral_constant<int, 1>{}, 1, 2 * hq + 1); }
+      if constexpr (J >= 1 && J <= 3) h_issue_h(std::integral_constant<int, J + 1>{}, 1, 2 * hq + 1);
+      if constexpr (J == 5) { if (hq + 1 < hq1) { h_issue_h(std::integral_constant<int, 0>{}, 0, 2 * hq + 2); h_issue_h(std::integral_constant<int, 1>{}, 0, 2 * hq + 2); } }
+      if constexpr (J >= 6) { if (hq + 1 < hq1) h_issue_h(std::integral_constant<int, J - 4>{}, 0, 2 * hq + 2); }
+      const char* sw = smem + wpar * H_WST;
+      bf16x8_t xf[2][TM], wf[2][TN];
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        const int it = 2 * J + g, hb = it >= 9 ? 1 : 0, tap = it % 9, ky = tap / 3, kx = tap - 3 * ky;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) xf[g][i] = *reinterpret_cast<const bf16x8_t*>(smem + H_BASE + hb * H_BYTES + ky * H_HP * 64 + aoff[kx][i]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) wf[g][j] = *reinterpret_cast<const bf16x8_t*>(sw + swz2(wn * WTN + j * 16 + r16h, 4 * g + q4h));
+        if (!GEMM2_DBG(2)) {
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int i = 0; i < TM; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[g][j], xf[g][i], acc[j][i], 0, 0, 0);
+        }
+      }
+      wpar ^= 1;
+      if constexpr (J == 8) ++hq;
+    };
+    for (;;) {
+      [&]<int... J>(std::integer_sequence<int, J...>) { (h_step(std::integral_constant<int, J>{}), ...); }(std::make_integer_sequence<int, 9>{});
+      if (hq >= hq1) break;
+    }
+  } else if constexpr (PPL) {
     ppfrag_t xa[2][PP_TMH], wb0[2][PP_TN0], wb1[2][PP_TN1 > 0 ? PP_TN1 : 1];
     auto ld_a = [&](const char* sa, int half) {
 #pragma unroll

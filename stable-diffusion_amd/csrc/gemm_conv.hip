@@ -470,6 +470,19 @@ extern "C" int sdamd_gemm_tile(int M, int N, int K, int batch, int dtype, size_t
   return choose_tile(M, N, batch);
 }
 
+// Host-only, as sdamd_gemm_tile: the image width (64 / 32 / 16) when sdamd_conv3x3 runs this problem on the halo-staged
+// kernel (gemm4.hip), else 0.
+extern "C" int sdamd_conv3x3_halo(int B, int H, int Wd, int Cin, int Cout, int stride, int pad_mode, int upsample, int dtype,
+                                  size_t ws_bytes) {
+  if (g_gemm_impl == 1 || dtype != SDAMD_BF16 || upsample || pad_mode != 0 || stride != 1 || B <= 0 || H <= 0 || Wd <= 0 || Cin % 64 != 0) return 0;
+  GemmArgs a = {};
+  a.M = B * H * Wd; a.N = Cout; a.K = 9 * Cin; a.ldw = a.K;
+  a.H = a.Ho = H; a.Wd = a.Wo = Wd; a.Cin = Cin; a.stride = 1; a.pad = 1;
+  int stages = 2;
+  if (gemm2_choose_tile(a.M, a.N, a.K, 1, g_gemm_impl, ws_bytes, &a.splits, 64, &stages) != 128160 || stages != 2) return 0;
+  return gemm2halo_width(a, 1);
+}
+
 template <typename T, bool CONV>
 static int pick_tile(GemmArgs& a, int batch, hipStream_t st) {
   switch (choose_tile(a.M, a.N, batch)) {

@@ -424,6 +424,53 @@ def test_conv3x3(dtype, B, Cin, Cout, H, W, stride, pad_mode, ups, res, gemm_imp
     assert rel_l2(from_nhwc(got), want.float()) < tol(dtype, 2e-6, 4e-3)
 
 
+@pytest.mark.parametrize("mode,B,Cin,Cout,HW,split", [(2, 2, 64, 160, 16, False), (2, 1, 128, 160, 32, False), (2, 1, 64, 160, 64, False),
+                                                      (2, 3, 192, 480, 16, False), (3, 2, 192, 160, 32, True), (0, 8, 320, 320, 64, False),
+                                                      (0, 16, 640, 1280, 16, True)])
+@pytest.mark.parametrize("form", ["bf16", "res_f32", "f32_stats"])
+def test_conv3x3_halo_staged(mode, B, Cin, Cout, HW, split, form, monkeypatch):
+    """The halo-staged conv3x3 (gemm4.hip: stride 1, pad 1, bf16, images 64 / 32 / 16 wide on the 128x160 tile) against
+    float64 and against the gathered kernel it replaces (library switch bit 23): every image border, tiles at the top and
+    bottom of an image, several images per launch, the 3-way K split (mode 3) and the planner's own choices at UNet shapes
+    (mode 0: 64x64 un-split, 16x16 with a 2-way split).  diffusion.py:9,13."""
+    from sd_amd import _lib
+    L = _lib.lib()
+    monkeypatch.setattr(ops, "PRODUCER_STATS_MIN_ELEMS", 0)   # (statistics whatever the size: un-split launches produce them)
+    x = q(rnd(f"halo.x.{Cin}.{HW}.{B}", (B, Cin, HW, HW)), torch.bfloat16)
+    w = q(rnd(f"halo.w.{Cin}.{Cout}", (Cout, Cin, 3, 3), 1.0 / math.sqrt(9 * Cin)), torch.bfloat16)
+    b = rnd(f"halo.b.{Cout}", (Cout,))
+    want = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+    kw = {}
+    if form == "res_f32":
+        r = rnd(f"halo.r.{Cout}.{HW}.{B}", tuple(want.shape))
+        want = want + r
+        kw = dict(residual=to_nhwc(r, torch.float32), out_f32=True)
+    elif form == "f32_stats":
+        kw = dict(out_f32=True, want_stats=True)
+    wp = w.permute(0, 2, 3, 1).reshape(Cout, -1).contiguous().bfloat16().to(DEV)
+    xn = to_nhwc(x, torch.bfloat16)
+    ws = ops._gemm_workspace(torch.device(DEV))
+    old = L.sdamd_set_gemm_impl(mode)
+    try:
+        assert L.sdamd_conv3x3_halo(B, HW, HW, Cin, Cout, 1, 0, 0, 1, ws.numel()) == HW
+        got = ops.conv3x3(xn, wp, b.to(DEV), **kw)
+        st = ops._stats_of(got)
+        L.sdamd_set_gemm_impl(mode | (8 << 20))
+        assert L.sdamd_conv3x3_halo(B, HW, HW, Cin, Cout, 1, 0, 0, 1, ws.numel()) == 0
+        gathered = ops.conv3x3(xn, wp, b.to(DEV), **kw)
+        st_g = ops._stats_of(gathered)
+    finally:
+        L.sdamd_set_gemm_impl(old)
+    f32 = form != "bf16"
+    assert got.dtype == (torch.float32 if f32 else torch.bfloat16)
+    assert rel_l2(from_nhwc(got), want.float()) < (2e-6 if f32 else 4e-3)
+    assert rel_l2(got.float().cpu(), gathered.float().cpu()) < (1e-6 if f32 else 2e-3)   # same products, another f32 summation order
+    assert (st is None) == (st_g is None) and (st is not None) == (form == "f32_stats" and not split)
+    if st is not None:   # per-64-row column sums of what was stored
+        rows = got.float().reshape(-1, 64, Cout)
+        assert torch.allclose(st.reshape(-1, Cout, 2)[..., 0].cpu(), rows.sum(1).cpu(), rtol=1e-4, atol=1e-3)
+
+
 def test_conv3x3_long_k_auto_split():
     """The 8x8-level UNet conv (M = 128 at UNet batch 2, K = 9*1280): the planner's own choice there is the 128x160 tile
     with an 8-way K split; bf16 operands, f32 residual and output."""
