@@ -29,12 +29,13 @@ for B, H, W, Cin, Cout in shapes:
     for label, kw in (("bf16out", dict()), ("+res f32", dict(residual=res, out_f32=True)), ("f32 stats", dict(out_f32=True, want_stats=True))):
         outs = {}
         row = []
-        for nm, impl in (("gather", OFF), ("halo", 0)):
+        for nm, impl in (("gather", OFF), ("halo", 2 << 20), ("hbw", 18 << 8)):
             L.sdamd_set_gemm_impl(impl)
             outs[nm] = ops.conv3x3(xs[0], w, b, **kw)
             ms = t(lambda i: ops.conv3x3(xs[i % NR], w, b, **kw), 2 * NR)
             row.append(f"{nm} {ms*1e3:6.1f}us {2.0*B*H*W*Cout*9*Cin/ms/1e9:5.0f}TF")
         d = (outs["halo"].float() - outs["gather"].float()).abs().max().item()
+        dh = (outs["hbw"].float() - outs["halo"].float()).abs().max().item()
         ref = torch.nn.functional.conv2d(xs[0].double().permute(0, 3, 1, 2)[:1], w.double().view(Cout, 3, 3, Cin).permute(0, 3, 1, 2), b.double(), padding=1).permute(0, 2, 3, 1)
         if "residual" in kw: ref = ref + res[:1].double()
         e = (outs["halo"][:1].double() - ref).abs().max().item()
@@ -43,5 +44,5 @@ for B, H, W, Cin, Cout in shapes:
         if "want_stats" in kw:
             sh, sg = ops._stats_of(outs["halo"]), ops._stats_of(outs["gather"])
             st = f" stats {'none' if sh is None else (sh.float() - sg.float()).abs().max().item() if sg is not None else 'halo only'}"
-        print(f"conv B{B} {H}x{W} {Cin}->{Cout} {label:9s}: " + " | ".join(row) + f" | max|halo-gather| {d:.2e} err vs f64 halo {e:.2e} gather {e0:.2e}{st}", flush=True)
+        print(f"conv B{B} {H}x{W} {Cin}->{Cout} {label:9s}: " + " | ".join(row) + f" | max|halo-gather| {d:.2e} |hbw-halo| {dh:.1e} err vs f64 halo {e:.2e} gather {e0:.2e}{st}", flush=True)
 L.sdamd_set_gemm_impl(0)

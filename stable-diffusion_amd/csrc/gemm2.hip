@@ -95,6 +95,15 @@ static int launch2(GemmArgs& a, int batch, hipStream_t st) {
       return -1;
     }
   }
+  // big-wave halo conv (gemm5.hip): every epilogue of EPI 0 (the residual, if any, is read in the epilogue)
+  if constexpr (CONV && std::is_same<T, bf16_t>::value && BM == 128 && BN == 160 && STAGES == 2) {
+    const int r = launch_gemm2hbw(a, batch, st);
+    if (r > 0) return r;
+    if (r == 0) {
+      if (a.splits > 1) return launch_splitk_reduce(a, st);
+      return 0;
+    }
+  }
   // residual-prefetch kernel (EPI 1): f32 residual + f32 / hi|lo output, no split, on the tiles with the registers for it
   constexpr bool HAS_RPRE = WGM * WGN == 4 || (!CONV && BM == 128 && BN == 320);
   if constexpr (HAS_RPRE) {

@@ -39,6 +39,24 @@ static __device__ __attribute__((aligned(256))) const unsigned int g_zero_page[H
 
 __device__ __forceinline__ int swz2(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
+// One LDS-DMA wave-instruction: 64 lanes x 16 bytes from per-lane global addresses to LDS bytes [lds, lds + 1024).
+// ASM = true issues it from inline assembly.  hipcc models the builtin as a FLAT access that may touch LDS: from the first
+// one on, its waitcnt pass regards the LGKM counter as out of order and every wait it inserts for an LDS read becomes
+// lgkmcnt(0) -- "ds_read, wait for everything, MFMA" even when the fragment was requested long ago and younger reads are
+// in flight.  Hidden in assembly, the DMA leaves the compiler's LDS bookkeeping alone (counted lgkmcnt waits); its
+// completion is the kernel's business either way (hand-counted vmcnt + s_barrier before the data is read).
+template <bool ASM> __device__ __forceinline__ void lds_dma16(const void* g, void* lds) {
+  if constexpr (ASM) {
+#ifdef HBW_NO_DMA
+    return;
+#endif
+    const unsigned l = (unsigned)(unsigned long)(lds_void_t*)lds;
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(l), "v"(g) : "memory", "m0");
+  } else {
+    __builtin_amdgcn_global_load_lds((gbl_void_t*)g, (lds_void_t*)lds, 16, 0, 0);
+  }
+}
+
 template <int N> __device__ __forceinline__ void wait_vmcnt() {
   static_assert(N >= 0 && N < 64, "vmcnt range");
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -66,12 +84,15 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
 // the launches WITHOUT a residual 6-13 us slower inside a UNet step, where consecutive launches are different
 // kernels, while a back-to-back microbenchmark saw nothing: code executed once per launch is not free.)
 // PP: 0 = the one-barrier-per-K-tile ring of the header; 1, 2 = the "ping-pong" main loop (see GEMM2 PING-PONG below);
-//     3, 4, 5 = the halo-staged conv3x3 loop for images 64, 32, 16 pixels wide (see GEMM2 HALO below).
+//     3, 4, 5 = the halo-staged conv3x3 loop for images 64, 32, 16 pixels wide (see GEMM2 HALO below);
+//     6, 7, 8 = the same on a 256-row tile with one wave per SIMD and a software-pipelined step (GEMM2 HALO BIG-WAVE).
 template <typename T, int BM, int BN, int WGM, int WGN, int STAGES, bool CONV, int EPI, int PP>
 __device__ __forceinline__ void gemm2_body(const GemmArgs& p) {
   constexpr bool PPL = PP == 1 || PP == 2;
-  constexpr int HALO_W = PP == 3 ? 64 : PP == 4 ? 32 : PP == 5 ? 16 : 0;
+  constexpr int HALO_W = (PP == 3 || PP == 6) ? 64 : (PP == 4 || PP == 7) ? 32 : (PP == 5 || PP == 8) ? 16 : 0;
   constexpr bool HALO = HALO_W != 0;
+  constexpr bool ASM_DMA = PP >= 6;        // LDS-DMA from inline assembly (lds_dma16)
+  constexpr bool HBW = PP >= 6;            // halo loop, one wave per SIMD with a 128x80 wave tile (see GEMM2 HALO BIG-WAVE)
   constexpr bool F32 = sizeof(T) == 4;     // exact-f32 MFMA (v_mfma_f32_16x16x4_f32) on f32 operands
   // f32 operands split into 3 bf16 terms, 6 bf16 MFMAs (split3_bf16).  WPL: the weight operand arrives split already
   // (GemmArgs::W3, three bf16 planes of 32 k = 64 bytes per row and K-tile), so only the activation fragments are split
@@ -201,11 +222,11 @@ __device__ __forceinline__ void gemm2_body(const GemmArgs& p) {
       } else {
         g = asrc[i] + k0;
       }
-      __builtin_amdgcn_global_load_lds((gbl_void_t*)g, (lds_void_t*)(stage + (wave + NW * i) * 1024), 16, 0, 0);
+      lds_dma16<ASM_DMA>(g, stage + (wave + NW * i) * 1024);
     } else {
       constexpr int i = PI - A_INS;
       if (B_PIECES % NW != 0 && i == B_INS - 1 && wave + NW * i >= B_PIECES) return;
-      __builtin_amdgcn_global_load_lds((gbl_void_t*)(wsrc[i] + k0 * (WPL ? 3 : 1)), (lds_void_t*)(stage + BM * 128 + (wave + NW * i) * 1024), 16, 0, 0);
+      lds_dma16<ASM_DMA>(wsrc[i] + k0 * (WPL ? 3 : 1), stage + BM * 128 + (wave + NW * i) * 1024);
     }
   };
   auto advance_k = [&]() { if (CONV) { cc += BKE; if (cc >= p.Cin) { cc = 0; ++tap; } } };
@@ -389,7 +410,9 @@ __device__ __forceinline__ void gemm2_body(const GemmArgs& p) {
   constexpr int H_WD = HALO ? HALO_W : BM;
   constexpr int H_HP = H_WD + 16, H_HR = BM / H_WD + 2;                  // halo row pitch (pixels) and rows
   constexpr int H_BYTES = H_HR * H_HP * 64, H_PIECES = H_BYTES / 1024, H_INS = (H_PIECES + NW - 1) / NW;
-  constexpr int H_WST = BN * 128, H_BASE = 2 * H_WST;                    // W ring stage; halo buffers behind the ring
+  constexpr int H_WST = BN * 128;                                        // one W ring stage
+  constexpr int H_S = HBW ? 4 : 2;                                       // W ring depth
+  constexpr int H_BASE = HBW ? 0 : 2 * H_WST, H_WBASE = HBW ? 2 * H_BYTES : 0;   // halo buffers / W ring inside smem
   [[maybe_unused]] const T* hsrc[H_INS];       // per-lane source of halo piece wave + NW*i at channel 0
   [[maybe_unused]] const TW* hwsrc[B_INS];     // per-lane source of W piece wave + NW*i at k = 0
   [[maybe_unused]] int aoff[3][TM];            // activation fragment offset inside a halo buffer, per kx and 16-row block
@@ -400,18 +423,20 @@ __device__ __forceinline__ void gemm2_body(const GemmArgs& p) {
     const int delta = wsel ? kb : ka;
 #pragma unroll
     for (int i = 0; i < B_INS; ++i)
-      __builtin_amdgcn_global_load_lds((gbl_void_t*)(hwsrc[i] + delta), (lds_void_t*)(smem + par * H_WST + (wave + NW * i) * 1024), 16, 0, 0);
+      lds_dma16<ASM_DMA>(hwsrc[i] + delta, smem + H_WBASE + par * H_WST + (wave + NW * i) * 1024);
   };
   [[maybe_unused]] auto h_issue_h = [&](auto IC, int hb, int chunk) {
     constexpr int i = decltype(IC)::value;
     if (GEMM2_DBG(1)) return;
     if (H_PIECES % NW != 0 && i == H_INS - 1 && wave + NW * i >= H_PIECES) return;
-    __builtin_amdgcn_global_load_lds((gbl_void_t*)(hsrc[i] + chunk * 32), (lds_void_t*)(smem + H_BASE + hb * H_BYTES + (wave + NW * i) * 1024), 16, 0, 0);
+    lds_dma16<ASM_DMA>(hsrc[i] + chunk * 32, smem + H_BASE + hb * H_BYTES + (wave + NW * i) * 1024);
   };
   if constexpr (HALO) {
-    static_assert(CONV && !F32 && !EMU && NW == 4 && WGM == 2 && BM == 128 && STAGES == 2 && B_PIECES % NW == 0 && BM % H_WD == 0 && H_WD % 16 == 0,
+    static_assert(CONV && !F32 && !EMU && NW == 4 && WGM == 2 && (BM == 128 || HBW) && STAGES == 2 && B_PIECES % NW == 0 && BM % H_WD == 0 && H_WD % 16 == 0,
                   "halo loop: bf16 conv on the 4-wave 128-row tile");
-    static_assert(H_BYTES % 1024 == 0 && H_INS == 5 && H_BASE + 2 * H_BYTES <= 80 * 1024, "halo loop: piece schedule / LDS budget (two workgroups per CU)");
+    static_assert(H_BYTES % 1024 == 0 && (HBW || (H_INS == 5 && H_BASE + 2 * H_BYTES <= 80 * 1024)), "halo loop: piece schedule / LDS budget (two workgroups per CU)");
+    static_assert(!HBW || EPI == 0, "big-wave halo loop: the counted waits assume no other vector-memory loads in flight (no residual prefetch)");
+    static_assert(!HBW || (BM == 256 && H_INS <= 9 && 2 * H_BYTES + H_S * H_WST <= 160 * 1024 && B_INS == 5), "big-wave halo loop: piece schedule / LDS budget");
     const int hw = p.Ho * p.Wo;
     const int n_img = m0 / hw, y0 = (m0 - n_img * hw) / HALO_W;
 #pragma unroll
@@ -445,7 +470,13 @@ __device__ __forceinline__ void gemm2_body(const GemmArgs& p) {
     hq = (int)((long long)ncyc * split / p.splits);
     hq1 = (int)((long long)ncyc * (split + 1) / p.splits);
     [&]<int... I>(std::integer_sequence<int, I...>) { (h_issue_h(std::integral_constant<int, I>{}, 0, 2 * hq), ...); }(std::make_integer_sequence<int, H_INS>{});
-    h_issue_w(0, hq * 64, p.Cin + hq * 64);
+    if constexpr (HBW) {   // both chunks of the first cycle, then the first H_S W tiles (a launch has >= 9 steps)
+      [&]<int... I>(std::integer_sequence<int, I...>) { (h_issue_h(std::integral_constant<int, I>{}, 1, 2 * hq + 1), ...); }(std::make_integer_sequence<int, H_INS>{});
+#pragma unroll
+      for (int t = 0; t < H_S; ++t) h_issue_w(t, (2 * t) * p.Cin + hq * 64, (2 * t + 1) * p.Cin + hq * 64);
+    } else {
+      h_issue_w(0, hq * 64, p.Cin + hq * 64);
+    }
   } else if constexpr (PPL) {
     static_assert(NW == 8 && WGM == 2 && STAGES == 2 && TM % 2 == 0 && !F32 && !EMU, "ping-pong: 8 waves as 2M x 4N, bf16, 2-stage ring");
     static_assert(A_PIECES % NW == 0 && B_PIECES % NW == 0 && A_INS % 2 == 0 && B_INS >= 2, "ping-pong: uniform DMA piece counts per wave");
@@ -495,7 +526,114 @@ __device__ __forceinline__ void gemm2_body(const GemmArgs& p) {
       for (int k = 0; k < (TM / E_IP) * E_IT; ++k) rpre[k] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     }
   }
-  if constexpr (HALO) {
+  if constexpr (HBW) {
+    // ---- GEMM2 HALO BIG-WAVE (PP 6 / 7 / 8): the halo loop on a 256 x 160 tile, 4 waves = ONE wave per SIMD, wave tile
+    // 128 x 80 (13 fragment reads per 40 MFMAs instead of 9 per 20; W staged once per 256 rows instead of 128).  With
+    // no second wave to hide behind, the step is software-pipelined inside the wave and scheduled by hand: an item
+    // (K = 32: 40 MFMAs) is 20 slots of two MFMAs, fenced by sched_barriers; slot k of an item also issues fragment read
+    // k of the NEXT item (two fragment register sets) and, in a step's second item, one LDS-DMA piece, so reads and DMA
+    // issue ride in the shadow of the matrix pipe.  The LDS-DMA is issued from inline assembly (lds_dma16<true>): with
+    // the builtin every LDS wait the compiler inserts is lgkmcnt(0).  The barrier of a step sits in its middle -- after
+    // item 0, before the first read of the NEXT step's W tile -- and the W ring is 4 deep: after barrier B(s) the slot
+    // of tile s is free (its second half sits in registers) and takes tile s + 4, so a tile has three steps to land.
+    // Counted wait at B(s): everything but the W pieces of the two younger tiles (10) and the halo pieces of the last
+    // window (3, issued AHEAD of that window's W pieces) has landed: tile s + 1, and every halo piece two windows old.
+    // Halo chunks: buffer 0 (even chunk) is last read through fragments loaded before B(4) and refilled in the windows
+    // after B(4), B(5), B(6) -> landed at B(8); buffer 1 (odd) is refilled after B(8), B(0), B(1) of the next cycle
+    // and first read after B(3).  A window issues exactly three halo pieces per wave (missing ones repeat the wave's
+    // piece 0: same bytes, same place).  s_waitcnt lgkmcnt(0) precedes every barrier: no LDS read of a wave is in
+    // flight when another wave's DMA into that slot can be issued.
+    const int r16h = lane & 15, q4h = lane >> 4;
+    int aoff1[3][TM];
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+      for (int i = 0; i < TM; ++i) aoff1[kx][i] = aoff[kx][i] + H_BYTES;
+    const int wfb0 = H_WBASE + swz2(wn * WTN + r16h, q4h), wfb1 = H_WBASE + swz2(wn * WTN + r16h, 4 + q4h);
+    bf16x8_t xf[2][TM], wf[2][TN];
+    const int hq0 = hq;
+    int wslot = 0, srem = (hq1 - hq) * 9 - 1;             // ring slot of the current step; steps after the current one
+    constexpr int NRD = TM + TN, NMF = TM * TN, NSLOT = NMF / 2;
+    static_assert(NMF % 2 == 0 && NRD <= NSLOT && B_INS + 3 <= NSLOT, "big-wave halo loop: slot schedule");
+    // fragment read R of item IT (0..17 of the cycle) into register set G, W tile in ring slot `slot`; order: W 0, A 0..TM-1, W 1..
+    auto rd = [&](auto GC, auto ITC, auto RC, int slot) {
+      constexpr int g = decltype(GC)::value, it = decltype(ITC)::value, r = decltype(RC)::value;
+      constexpr int hb = it >= 9 ? 1 : 0, tap = it % 9, ky = tap / 3, kx = tap - 3 * ky;
+      if constexpr (r == 0 || r > TM) {
+        constexpr int j = r == 0 ? 0 : r - TM;
+        wf[g][j] = *reinterpret_cast<const bf16x8_t*>(smem + slot * H_WST + ((it & 1) ? wfb1 : wfb0) + j * 2048);
+      } else {
+        constexpr int i = r - 1;
+        xf[g][i] = *reinterpret_cast<const bf16x8_t*>(smem + H_BASE + ky * H_HP * 64 + (hb ? aoff1[kx][i] : aoff[kx][i]));
+      }
+    };
+    auto mf = [&](auto GC, auto NC) {
+      constexpr int g = decltype(GC)::value, n = decltype(NC)::value, j = n / TM, i = n % TM;
+      acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[g][j], xf[g][i], acc[j][i], 0, 0, 0);
+    };
+    // one item: MFMAs on set G, fragment reads of item ITN into the other set, `extra(k)` in slot k (DMA issue)
+    auto item = [&](auto GC, auto ITN, int slot, auto&& extra) {
+      constexpr int g = decltype(GC)::value;
+      [&]<int... K>(std::integer_sequence<int, K...>) {
+        ([&] {
+          if constexpr (K < NRD) rd(std::integral_constant<int, 1 - g>{}, ITN, std::integral_constant<int, K>{}, slot);
+          extra(std::integral_constant<int, K>{});
+          mf(GC, std::integral_constant<int, 2 * K>{});
+          mf(GC, std::integral_constant<int, 2 * K + 1>{});
+          __builtin_amdgcn_sched_barrier(0);
+        }(), ...);
+      }(std::make_integer_sequence<int, NSLOT>{});
+    };
+    auto halo3 = [&](auto KC, auto FIRST, int hb, int chunk) {   // slot KC (0..2) of a halo window whose first piece slot is FIRST
+      constexpr int k = decltype(KC)::value, i = decltype(FIRST)::value + k;
+      if constexpr (i < H_INS) {
+        if (H_PIECES % NW == 0 || i < H_INS - 1 || wave + NW * i < H_PIECES) { h_issue_h(std::integral_constant<int, i>{}, hb, chunk); return; }
+      }
+      h_issue_h(std::integral_constant<int, 0>{}, hb, chunk);
+    };
+    using C0 = std::integral_constant<int, 0>;
+    using C1 = std::integral_constant<int, 1>;
+    wait_vmcnt<(H_S - 1) * B_INS>();     // halo chunks + W tile 0 landed
+    __builtin_amdgcn_s_barrier();
+    [&]<int... R>(std::integer_sequence<int, R...>) { (rd(C0{}, C0{}, std::integral_constant<int, R>{}, 0), ...); }(std::make_integer_sequence<int, NRD>{});
+    auto hb_step = [&](auto JC) {
+      constexpr int J = decltype(JC)::value;
+      // item 0: MFMAs of item 2J (set 0), reads of item 2J + 1 (set 1, same W tile)
+      item(C0{}, std::integral_constant<int, 2 * J + 1>{}, wslot, [](auto) {});
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      // B(s): tile s + 1 and every halo piece two windows old have landed
+      const bool hprev = (J == 0 || J == 1 || J == 2) ? hq > hq0 : (J >= 5 && J <= 7) ? hq + 1 < hq1 : false;
+      if (srem >= 3) { if (hprev) wait_vmcnt<2 * B_INS + 3>(); else wait_vmcnt<2 * B_INS>(); }
+      else if (srem == 2) wait_vmcnt<B_INS>();
+      else wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();
+      // item 1: MFMAs of item 2J + 1 (set 1), reads of the next step's first item (set 0, next W tile), this window's DMA
+      const int nslot = (wslot + 1) & (H_S - 1);
+      const bool wmore = srem >= H_S;
+      constexpr int nj = (J + H_S) % 9, ia = 2 * nj, ib = ia + 1;
+      const int kq = (hq + (J + H_S >= 9 ? 1 : 0)) * 64;
+      const int wdelta = wsel ? (ib % 9) * p.Cin + kq + (ib >= 9 ? 32 : 0) : (ia % 9) * p.Cin + kq + (ia >= 9 ? 32 : 0);
+      constexpr bool HWIN = J <= 1 || (J >= 4 && J <= 6) || J == 8;                 // a halo window
+      const bool hact = J <= 1 ? hq > hq0 : hq + 1 < hq1;                             // ... that has a chunk to fetch
+      constexpr int hfirst = J <= 1 ? 3 * (J + 1) : J == 8 ? 0 : 3 * (J - 4);
+      constexpr int hbuf = (J >= 4 && J <= 6) ? 0 : 1;
+      const int hchunk = J <= 1 ? 2 * hq + 1 : J == 8 ? 2 * hq + 3 : 2 * hq + 2;
+      item(C1{}, std::integral_constant<int, 2 * ((J + 1) % 9)>{}, nslot, [&](auto KC) {
+        constexpr int k = decltype(KC)::value;
+        if constexpr (HWIN && k < 3) { if (hact) halo3(KC, std::integral_constant<int, hfirst>{}, hbuf, hchunk); }
+        if constexpr (k >= 3 && k < 3 + B_INS) {
+          if (wmore && !GEMM2_DBG(1)) lds_dma16<true>(hwsrc[k - 3] + wdelta, smem + H_WBASE + wslot * H_WST + (wave + NW * (k - 3)) * 1024);
+        }
+      });
+      wslot = nslot;
+      --srem;
+      if constexpr (J == 8) ++hq;
+    };
+    for (;;) {
+      [&]<int... J>(std::integer_sequence<int, J...>) { (hb_step(std::integral_constant<int, J>{}), ...); }(std::make_integer_sequence<int, 9>{});
+      if (hq >= hq1) break;
+    }
+  } else if constexpr (HALO) {
     const int r16h = lane & 15, q4h = lane >> 4;
     auto h_step = [&](auto JC) {
       constexpr int J = decltype(JC)::value;
@@ -876,7 +1014,7 @@ __device__ __forceinline__ void gemm2_body(const GemmArgs& p) {
   } else if constexpr (EPI == 0) {
     constexpr int RS = WTN * 2 + 16;
     constexpr int IPMAX = (STAGES * STAGE / NW) / (16 * RS);
-    constexpr int IP = IPMAX >= TM ? TM : (IPMAX >= TM / 2 && TM % 2 == 0) ? TM / 2 : (IPMAX >= TM / 4 && TM % 4 == 0) ? TM / 4 : 1;
+    constexpr int IP = (IPMAX >= TM && TM <= 4) ? TM : (IPMAX >= TM / 2 && TM % 2 == 0) ? TM / 2 : (IPMAX >= TM / 4 && TM % 4 == 0) ? TM / 4 : 1;   // (at most one 64-row block per pass)
     static_assert(IPMAX >= 1, "epilogue staging does not fit");
     constexpr int CPR = WTN / 8;
     static_assert(WTM % 64 != 0 || 64 % (IP * 16) == 0, "column statistics: an epilogue pass must not span two 64-row blocks");

@@ -1,0 +1,37 @@
+// Big-wave instantiation of the halo-staged conv3x3 (gemm2_kernel.h, "GEMM2 HALO BIG-WAVE"): 256 x 160 tile, 4 waves =
+// one per SIMD, wave tile 128 x 80 with the accumulators in AGPRs (this file is built WITHOUT -amdgpu-mfma-vgpr-form),
+// software-pipelined step, 4-deep W ring.  Same results as gemm4.hip's kernels (same K order per output element).
+#include "gemm2_kernel.h"
+
+__global__ __launch_bounds__(256) void gemm2hbw_kernel(const GemmArgs p) {
+  if (p.Wo == 64) gemm2_body<bf16_t, 256, 160, 2, 2, 2, true, 0, 6>(p);
+  else if (p.Wo == 32) gemm2_body<bf16_t, 256, 160, 2, 2, 2, true, 0, 7>(p);
+  else gemm2_body<bf16_t, 256, 160, 2, 2, 2, true, 0, 8>(p);
+}
+
+static constexpr int hbw_lds(int w) { return 4 * 160 * 128 + 2 * (256 / w + 2) * (w + 16) * 64; }
+
+// `a` planned for the 128x160 tile (tiles_n, splits); takes it when the halo form would and the image rows tile 256 pixels
+bool gemm2hbw_takes(const GemmArgs& a, int batch) {
+  extern int g_gemm_pp, g_gemm_debug;
+  if ((g_gemm_pp & 2) || !gemm2halo_width(a, batch)) return false;
+  if ((a.Ho * a.Wo) % 256 != 0 || a.M % 256 != 0) return false;
+  // One workgroup per CU: prologue and epilogue are exposed, so short K loops (Cin 320: 45 steps) stay on the 128-row
+  // halo kernel with its two workgroups per CU (measured: 64x64 320->320 133 vs 118 us; from Cin 640 on this one wins)
+  // (and the 64x64-level convs with an f32 residual: 84 MB read + 84 MB written in an epilogue nothing overlaps, 226 vs 221 us)
+  return (a.Cin >= 640 && !(a.Wo == 64 && a.R)) || g_gemm_debug == 18;
+}
+
+int launch_gemm2hbw(GemmArgs& a, int batch, hipStream_t st) {
+  if (!gemm2hbw_takes(a, batch)) return -1;
+  constexpr int lds = hbw_lds(16);
+  static_assert(hbw_lds(16) <= 160 * 1024 && hbw_lds(64) <= lds && hbw_lds(32) <= lds, "gemm2hbw: LDS budget");
+  static std::atomic<unsigned long long> lds_ok{0};
+  if (sd_lds_opt_in(lds_ok, (const void*)gemm2hbw_kernel, lds) != hipSuccess)
+    return sdamd_set_error(2, "gemm2hbw: cannot reserve %d bytes of LDS", lds);
+  a.tiles_m = a.M / 256;
+  dim3 grid(a.tiles_m * a.tiles_n, 1, a.splits);
+  gemm2hbw_kernel<<<grid, 256, hbw_lds(a.Wo), st>>>(a);
+  SD_LAUNCH_CHECK("gemm2hbw");
+  return 0;
+}

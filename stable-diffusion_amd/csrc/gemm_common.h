@@ -78,6 +78,8 @@ int launch_gemm2pp(GemmArgs& a, int tile, int batch, bool conv, hipStream_t st);
 // gemm4.hip: the halo-staged conv3x3 on the 4-wave 128x160 tile (bf16, stride 1, pad 1, images 64 / 32 / 16 wide);
 // `a` planned as for gemm2_kernel<bf16, 128, 160, 2, 2, 2, true, epi>; -1 = not taken
 int launch_gemm2halo(const GemmArgs& a, int epi, int batch, hipStream_t st);
+int launch_gemm2hbw(GemmArgs& a, int batch, hipStream_t st);
+bool gemm2hbw_takes(const GemmArgs& a, int batch);   // gemm5.hip: 256-row one-wave-per-SIMD form (sets tiles_m)
 int gemm2halo_width(const GemmArgs& a, int batch);   // 64 / 32 / 16 when the halo form takes the (planned) launch, else 0
 
 // out = act(sum_s ws[s] + bias + residual) for a split-K launch (gemm2.hip)

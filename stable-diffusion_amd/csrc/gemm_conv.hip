@@ -418,7 +418,8 @@ int g_gemm_debug = 0;
 int g_f32_emu = 1;
 extern "C" int sdamd_set_f32_mode(int mode) { int old = g_f32_emu; if (mode == 0 || mode == 1) g_f32_emu = mode; return old; }
 // Ping-pong kernels (gemm3.hip) for the 256x256 launches (GeGLU GEMMs, VAE / CLIP widths): bit 0 = on (default),
-// bit 2 = the variant that re-reads the B0 fragments.  sdamd_set_gemm_impl carries `g_gemm_pp ^ 1` in bits 20-23, so an
+// bit 2 = the variant that re-reads the B0 fragments; bit 1 = the big-wave halo conv (gemm5.hip) OFF, bit 3 = every
+// halo-staged conv (gemm4.hip, gemm5.hip) OFF (A/B runs and tests).  sdamd_set_gemm_impl carries `g_gemm_pp ^ 1` in bits 20-23, so an
 // impl word without those bits (every existing caller) keeps the default and bit 20 switches the kernels OFF (A/B runs).
 int g_gemm_pp = 1;
 extern "C" int sdamd_set_gemm_impl(int impl) {
@@ -470,8 +471,8 @@ extern "C" int sdamd_gemm_tile(int M, int N, int K, int batch, int dtype, size_t
   return choose_tile(M, N, batch);
 }
 
-// Host-only, as sdamd_gemm_tile: the image width (64 / 32 / 16) when sdamd_conv3x3 runs this problem on the halo-staged
-// kernel (gemm4.hip), else 0.
+// Host-only, as sdamd_gemm_tile: the image width (64 / 32 / 16) when sdamd_conv3x3 runs this problem on a halo-staged
+// kernel (gemm4.hip; + 256 when it is the 256-row big-wave kernel of gemm5.hip), else 0.
 extern "C" int sdamd_conv3x3_halo(int B, int H, int Wd, int Cin, int Cout, int stride, int pad_mode, int upsample, int dtype,
                                   size_t ws_bytes) {
   if (g_gemm_impl == 1 || dtype != SDAMD_BF16 || upsample || pad_mode != 0 || stride != 1 || B <= 0 || H <= 0 || Wd <= 0 || Cin % 64 != 0) return 0;
@@ -480,7 +481,8 @@ extern "C" int sdamd_conv3x3_halo(int B, int H, int Wd, int Cin, int Cout, int s
   a.H = a.Ho = H; a.Wd = a.Wo = Wd; a.Cin = Cin; a.stride = 1; a.pad = 1;
   int stages = 2;
   if (gemm2_choose_tile(a.M, a.N, a.K, 1, g_gemm_impl, ws_bytes, &a.splits, 64, &stages) != 128160 || stages != 2) return 0;
-  return gemm2halo_width(a, 1);
+  const int w = gemm2halo_width(a, 1);
+  return w && gemm2hbw_takes(a, 1) ? w | 0x100 : w;   // bit 8: the 256-row big-wave kernel (gemm5.hip)
 }
 
 template <typename T, bool CONV>

@@ -621,6 +621,10 @@ def geglu_pack(t):
     return torch.stack([v.reshape((F2 // 32, 16) + tail), g.reshape((F2 // 32, 16) + tail)], 1).reshape(t.shape).contiguous()
 
 
+def _halo_tag(h):
+    return "_hbw" if h & 0x100 else "_halo" if h else ""
+
+
 def conv3x3(x, w, bias, residual=None, stride=1, pad_mode=0, upsample=False, act=ACT_NONE, out_f32=False, flops_cin=None,
             want_stats=False):
     """x [B,H,W,Cin] NHWC, w [Cout, 9*Cin] ([Cout][ky][kx][Cin]) -> [B,Ho,Wo,Cout].
@@ -652,9 +656,9 @@ def conv3x3(x, w, bias, residual=None, stride=1, pad_mode=0, upsample=False, act
     stats, wrote = _stats_request(want_stats and upsample != 2, M, Cout, x.device)
     w3 = weight_planes(w)
     # algorithmic FLOPs = the reference's nn.Conv2d (3x3 taps, un-split Cin), also for the 4/9-MAC phase form
-    # (label suffix _halo: the halo-staged kernel of gemm4.hip takes the launch)
+    # (label suffix _halo / _hbw: the halo-staged kernels of gemm4.hip / gemm5.hip take the launch)
     _timed(lambda: f"conv3x3_{_dt(x.dtype)}_{_tile_tag(M, Cout, 9 * Cin, x.dtype, ws, f32_residual=residual is not None and out.dtype == torch.float32, conv=True)}"
-                   + ("_halo" if _lib.lib().sdamd_conv3x3_halo(B, H, W, Cin, Cout, stride, pad_mode, upsample, _code(x.dtype), ws.numel()) else ""),
+                   + _halo_tag(_lib.lib().sdamd_conv3x3_halo(B, H, W, Cin, Cout, stride, pad_mode, upsample, _code(x.dtype), ws.numel())),
            2.0 * M * Cout * 9 * (Cin if flops_cin is None else flops_cin),
            lambda: _lib.check(_lib.lib().sdamd_conv3x3(_p(x), _p(w), _p(out), _p(bias), _p(residual), B, H, W, Cin, Cout, stride,
                                                        pad_mode, upsample, int(act), _code(x.dtype), int(out_f32),

@@ -424,15 +424,17 @@ def test_conv3x3(dtype, B, Cin, Cout, H, W, stride, pad_mode, ups, res, gemm_imp
     assert rel_l2(from_nhwc(got), want.float()) < tol(dtype, 2e-6, 4e-3)
 
 
-@pytest.mark.parametrize("mode,B,Cin,Cout,HW,split", [(2, 2, 64, 160, 16, False), (2, 1, 128, 160, 32, False), (2, 1, 64, 160, 64, False),
-                                                      (2, 3, 192, 480, 16, False), (3, 2, 192, 160, 32, True), (0, 8, 320, 320, 64, False),
-                                                      (0, 16, 640, 1280, 16, True)])
+@pytest.mark.parametrize("mode,B,Cin,Cout,HW,split,big", [(2, 2, 64, 160, 16, False, False), (2, 1, 128, 160, 32, False, False), (2, 1, 64, 160, 64, False, False),
+                                                          (2, 3, 192, 480, 16, False, False), (3, 2, 192, 160, 32, True, False), (0, 8, 320, 320, 64, False, False),
+                                                          (0, 16, 640, 1280, 16, True, True), (2, 2, 640, 160, 16, False, True), (2, 1, 640, 480, 32, False, True),
+                                                          (2, 1, 704, 160, 64, False, True), (3, 2, 768, 160, 32, True, True)])
 @pytest.mark.parametrize("form", ["bf16", "res_f32", "f32_stats"])
-def test_conv3x3_halo_staged(mode, B, Cin, Cout, HW, split, form, monkeypatch):
-    """The halo-staged conv3x3 (gemm4.hip: stride 1, pad 1, bf16, images 64 / 32 / 16 wide on the 128x160 tile) against
-    float64 and against the gathered kernel it replaces (library switch bit 23): every image border, tiles at the top and
-    bottom of an image, several images per launch, the 3-way K split (mode 3) and the planner's own choices at UNet shapes
-    (mode 0: 64x64 un-split, 16x16 with a 2-way split).  diffusion.py:9,13."""
+def test_conv3x3_halo_staged(mode, B, Cin, Cout, HW, split, big, form, monkeypatch):
+    """The halo-staged conv3x3 kernels (stride 1, pad 1, bf16, images 64 / 32 / 16 wide: gemm4.hip on the 128x160 tile,
+    gemm5.hip -- `big`, Cin >= 640 -- on the 256x160 one-wave-per-SIMD tile) against float64, against each other (same K
+    order: bit-equal) and against the gathered kernel they replace (library switch bits 21 / 23): every image border,
+    tiles at the top and bottom of an image, several images per launch, odd cycle counts (Cin 704), the 3-way K split
+    (mode 3) and the planner's own choices at UNet shapes (mode 0).  diffusion.py:9,13."""
     from sd_amd import _lib
     L = _lib.lib()
     monkeypatch.setattr(ops, "PRODUCER_STATS_MIN_ELEMS", 0)   # (statistics whatever the size: un-split launches produce them)
@@ -452,10 +454,13 @@ def test_conv3x3_halo_staged(mode, B, Cin, Cout, HW, split, form, monkeypatch):
     ws = ops._gemm_workspace(torch.device(DEV))
     old = L.sdamd_set_gemm_impl(mode)
     try:
-        assert L.sdamd_conv3x3_halo(B, HW, HW, Cin, Cout, 1, 0, 0, 1, ws.numel()) == HW
+        assert L.sdamd_conv3x3_halo(B, HW, HW, Cin, Cout, 1, 0, 0, 1, ws.numel()) == (HW | 0x100 if big else HW)
         got = ops.conv3x3(xn, wp, b.to(DEV), **kw)
         st = ops._stats_of(got)
-        L.sdamd_set_gemm_impl(mode | (8 << 20))
+        L.sdamd_set_gemm_impl(mode | (2 << 20))    # the 128-row halo kernel only
+        assert L.sdamd_conv3x3_halo(B, HW, HW, Cin, Cout, 1, 0, 0, 1, ws.numel()) == HW
+        small = ops.conv3x3(xn, wp, b.to(DEV), **kw)
+        L.sdamd_set_gemm_impl(mode | (8 << 20))    # the gathered kernel
         assert L.sdamd_conv3x3_halo(B, HW, HW, Cin, Cout, 1, 0, 0, 1, ws.numel()) == 0
         gathered = ops.conv3x3(xn, wp, b.to(DEV), **kw)
         st_g = ops._stats_of(gathered)
@@ -464,6 +469,7 @@ def test_conv3x3_halo_staged(mode, B, Cin, Cout, HW, split, form, monkeypatch):
     f32 = form != "bf16"
     assert got.dtype == (torch.float32 if f32 else torch.bfloat16)
     assert rel_l2(from_nhwc(got), want.float()) < (2e-6 if f32 else 4e-3)
+    assert torch.equal(got, small)                                                        # same K order per output element
     assert rel_l2(got.float().cpu(), gathered.float().cpu()) < (1e-6 if f32 else 2e-3)   # same products, another f32 summation order
     assert (st is None) == (st_g is None) and (st is not None) == (form == "f32_stats" and not split)
     if st is not None:   # per-64-row column sums of what was stored
