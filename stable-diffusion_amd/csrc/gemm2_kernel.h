@@ -91,7 +91,7 @@ __device__ __forceinline__ void gemm2_body(const GemmArgs& p) {
   constexpr bool PPL = PP == 1 || PP == 2;
   constexpr int HALO_W = (PP == 3 || PP == 6) ? 64 : (PP == 4 || PP == 7) ? 32 : (PP == 5 || PP == 8) ? 16 : 0;
   constexpr bool HALO = HALO_W != 0;
-  constexpr bool ASM_DMA = PP >= 6;        // LDS-DMA from inline assembly (lds_dma16)
+  constexpr bool ASM_DMA = PP >= 6;        // LDS-DMA from inline assembly (lds_dma16); measured on every other kernel: bit-equal results, no gain (+0.0 ... +0.2 % per UNet step)
   constexpr bool HBW = PP >= 6;            // halo loop, one wave per SIMD with a 128x80 wave tile (see GEMM2 HALO BIG-WAVE)
   constexpr bool F32 = sizeof(T) == 4;     // exact-f32 MFMA (v_mfma_f32_16x16x4_f32) on f32 operands
   // f32 operands split into 3 bf16 terms, 6 bf16 MFMAs (split3_bf16).  WPL: the weight operand arrives split already

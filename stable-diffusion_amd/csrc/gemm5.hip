@@ -16,10 +16,11 @@ bool gemm2hbw_takes(const GemmArgs& a, int batch) {
   extern int g_gemm_pp, g_gemm_debug;
   if ((g_gemm_pp & 2) || !gemm2halo_width(a, batch)) return false;
   if ((a.Ho * a.Wo) % 256 != 0 || a.M % 256 != 0) return false;
-  // One workgroup per CU: prologue and epilogue are exposed, so short K loops (Cin 320: 45 steps) stay on the 128-row
-  // halo kernel with its two workgroups per CU (measured: 64x64 320->320 133 vs 118 us; from Cin 640 on this one wins)
-  // (and the 64x64-level convs with an f32 residual: 84 MB read + 84 MB written in an epilogue nothing overlaps, 226 vs 221 us)
-  return (a.Cin >= 640 && !(a.Wo == 64 && a.R)) || g_gemm_debug == 18;
+  // One workgroup per CU: prologue (140 KB of DMA before the first MFMA) and epilogue are exposed, nothing else runs on the
+  // CU meanwhile.  In situ (captured UNet step, batch 16, per launch against the 128-row halo kernel): K = 9 * 1280 and
+  // up -5 ... -14 %, every 16x16-level launch (2-way K split, partial-sum epilogue) -9 ... -14 %, K = 9 * 960 +-0,
+  // K = 9 * 640 +3.5 ... +7 %: so from Cin 1280 on, and the whole 16x16 level.
+  return a.Cin >= 1280 || (a.Wo == 16 && a.Cin >= 640) || g_gemm_debug == 18;
 }
 
 int launch_gemm2hbw(GemmArgs& a, int batch, hipStream_t st) {

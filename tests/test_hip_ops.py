@@ -426,14 +426,14 @@ def test_conv3x3(dtype, B, Cin, Cout, H, W, stride, pad_mode, ups, res, gemm_imp
 
 @pytest.mark.parametrize("mode,B,Cin,Cout,HW,split,big", [(2, 2, 64, 160, 16, False, False), (2, 1, 128, 160, 32, False, False), (2, 1, 64, 160, 64, False, False),
                                                           (2, 3, 192, 480, 16, False, False), (3, 2, 192, 160, 32, True, False), (0, 8, 320, 320, 64, False, False),
-                                                          (0, 16, 640, 1280, 16, True, True), (2, 2, 640, 160, 16, False, True), (2, 1, 640, 480, 32, False, True),
-                                                          (2, 1, 704, 160, 64, False, True), (3, 2, 768, 160, 32, True, True)])
+                                                          (0, 16, 640, 1280, 16, True, True), (2, 2, 640, 160, 16, False, True), (2, 1, 1280, 480, 32, False, True),
+                                                          (2, 1, 1344, 160, 64, False, True), (3, 2, 1344, 160, 32, True, True), (2, 1, 640, 160, 32, False, False)])
 @pytest.mark.parametrize("form", ["bf16", "res_f32", "f32_stats"])
 def test_conv3x3_halo_staged(mode, B, Cin, Cout, HW, split, big, form, monkeypatch):
     """The halo-staged conv3x3 kernels (stride 1, pad 1, bf16, images 64 / 32 / 16 wide: gemm4.hip on the 128x160 tile,
-    gemm5.hip -- `big`, Cin >= 640 -- on the 256x160 one-wave-per-SIMD tile) against float64, against each other (same K
+    gemm5.hip -- `big`, Cin >= 1280 or 16-wide images from Cin 640 -- on the 256x160 one-wave-per-SIMD tile) against float64, against each other (same K
     order: bit-equal) and against the gathered kernel they replace (library switch bits 21 / 23): every image border,
-    tiles at the top and bottom of an image, several images per launch, odd cycle counts (Cin 704), the 3-way K split
+    tiles at the top and bottom of an image, several images per launch, odd cycle counts (Cin 1344), the 3-way K split
     (mode 3) and the planner's own choices at UNet shapes (mode 0).  diffusion.py:9,13."""
     from sd_amd import _lib
     L = _lib.lib()
