@@ -79,7 +79,7 @@ def kernel_symbol(kind):
         return f"gemm_kernel<{t}, {bm}, {bn}, {conv}>"
     if parts[0] == "attention":
         t = "unsigned short" if parts[1] == "bf16" else "float"
-        return f"attn_kernel<{t}, {parts[2][1:]}>"
+        return f"attn_kernel<{t}, {parts[2][1:]}, false>"    # (third argument: the reference-tracking instantiation, tests only)
     return kind
 
 def pmc_traffic(symbol):

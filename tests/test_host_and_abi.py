@@ -141,7 +141,7 @@ def test_bench_labels_map_to_kernel_symbols():
     assert ks("gemm_f32_128x160") == "gemm2_kernel<float, 128, 160, 2, 2, 2, false, 0>"
     assert ks("gemm_f32_64x64") == "gemm_kernel<float, 64, 64, false>"
     assert ks("conv3x3_bf16_256x320") == "gemm2_kernel<unsigned short, 256, 320, 4, 2, 2, true, 0>"
-    assert ks("attention_bf16_d40") == "attn_kernel<unsigned short, 40>"
+    assert ks("attention_bf16_d40") == "attn_kernel<unsigned short, 40, false>"
     assert ks("groupnorm_f32") == "groupnorm_f32"
     traffic, source = bench.pmc_traffic("gemm2_kernel<unsigned short, 128, 160, 2, 2, 2, true, 0>")
     assert (traffic is None and source is None) or (traffic > 1e8 and source.endswith("_pmc_traffic.json"))        # profiles/r01_pmc_traffic.json carries the dominant kernel under this name
