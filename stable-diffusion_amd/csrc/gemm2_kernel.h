@@ -85,11 +85,14 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
 // kernels, while a back-to-back microbenchmark saw nothing: code executed once per launch is not free.)
 // PP: 0 = the one-barrier-per-K-tile ring of the header; 1, 2 = the "ping-pong" main loop (see GEMM2 PING-PONG below);
 //     3, 4, 5 = the halo-staged conv3x3 loop for images 64, 32, 16 pixels wide (see GEMM2 HALO below);
-//     6, 7, 8 = the same on a 256-row tile with one wave per SIMD and a software-pipelined step (GEMM2 HALO BIG-WAVE).
+//     6, 7, 8 = the same on a 256-row tile with one wave per SIMD and a software-pipelined step (GEMM2 HALO BIG-WAVE);
+//     9, 10 = the big-wave loop on the phase-decomposed upsample conv (p.phase_up; low-resolution images 32, 16 wide).
 template <typename T, int BM, int BN, int WGM, int WGN, int STAGES, bool CONV, int EPI, int PP>
 __device__ __forceinline__ void gemm2_body(const GemmArgs& p) {
   constexpr bool PPL = PP == 1 || PP == 2;
-  constexpr int HALO_W = (PP == 3 || PP == 6) ? 64 : (PP == 4 || PP == 7) ? 32 : (PP == 5 || PP == 8) ? 16 : 0;
+  constexpr int HALO_W = (PP == 3 || PP == 6) ? 64 : (PP == 4 || PP == 7 || PP == 9) ? 32 : (PP == 5 || PP == 8 || PP == 10) ? 16 : 0;
+  constexpr bool HUP = PP >= 9;            // big-wave halo loop on the phase form of upsample + conv3x3: 4 taps (2 x 2) per phase
+  constexpr int H_NT = HUP ? 4 : 9;        // filter taps = items per 32-channel chunk = steps per cycle of two chunks
   constexpr bool HALO = HALO_W != 0;
   constexpr bool ASM_DMA = PP >= 6;        // LDS-DMA from inline assembly (lds_dma16); measured on every other kernel: bit-equal results, no gain (+0.0 ... +0.2 % per UNet step)
   constexpr bool HBW = PP >= 6;            // halo loop, one wave per SIMD with a 128x80 wave tile (see GEMM2 HALO BIG-WAVE)
@@ -436,6 +439,7 @@ __device__ __forceinline__ void gemm2_body(const GemmArgs& p) {
                   "halo loop: bf16 conv on the 4-wave 128-row tile");
     static_assert(H_BYTES % 1024 == 0 && (HBW || (H_INS == 5 && H_BASE + 2 * H_BYTES <= 80 * 1024)), "halo loop: piece schedule / LDS budget (two workgroups per CU)");
     static_assert(!HBW || EPI == 0, "big-wave halo loop: the counted waits assume no other vector-memory loads in flight (no residual prefetch)");
+    static_assert(!HUP || (EPI == 0 && H_NT >= H_S), "phase form: EPI 0 only (out_row), and a launch has >= H_S steps");
     static_assert(!HBW || (BM == 256 && H_INS <= 9 && 2 * H_BYTES + H_S * H_WST <= 160 * 1024 && B_INS == 5), "big-wave halo loop: piece schedule / LDS budget");
     const int hw = p.Ho * p.Wo;
     const int n_img = m0 / hw, y0 = (m0 - n_img * hw) / HALO_W;
@@ -462,7 +466,9 @@ __device__ __forceinline__ void gemm2_body(const GemmArgs& p) {
       const int yl = ml / HALO_W, xl = ml - yl * HALO_W;
 #pragma unroll
       for (int kx = 0; kx < 3; ++kx) {
-        const int hp = yl * H_HP + xl + kx;
+        // (phase form: tap (dy, dx) of phase (py, px) reads input pixel (y - 1 + py + dy, x - 1 + px + dx): the 3x3 form's
+        //  (ky, kx) = (py + dy, px + dx), so the phase only shifts the lane's base slot)
+        const int hp = (yl + (HUP ? py : 0)) * H_HP + xl + (HUP ? px : 0) + kx;
         aoff[kx][i] = hp * 64 + ((((lane >> 4) ^ (hp >> 2)) & 3) << 4);
       }
     }
@@ -473,7 +479,8 @@ __device__ __forceinline__ void gemm2_body(const GemmArgs& p) {
     if constexpr (HBW) {   // both chunks of the first cycle, then the first H_S W tiles (a launch has >= 9 steps)
       [&]<int... I>(std::integer_sequence<int, I...>) { (h_issue_h(std::integral_constant<int, I>{}, 1, 2 * hq + 1), ...); }(std::make_integer_sequence<int, H_INS>{});
 #pragma unroll
-      for (int t = 0; t < H_S; ++t) h_issue_w(t, (2 * t) * p.Cin + hq * 64, (2 * t + 1) * p.Cin + hq * 64);
+      for (int t = 0; t < H_S; ++t)
+        h_issue_w(t, ((2 * t) % H_NT) * p.Cin + hq * 64 + (2 * t >= H_NT ? 32 : 0), ((2 * t + 1) % H_NT) * p.Cin + hq * 64 + (2 * t + 1 >= H_NT ? 32 : 0));
     } else {
       h_issue_w(0, hq * 64, p.Cin + hq * 64);
     }
@@ -552,13 +559,15 @@ __device__ __forceinline__ void gemm2_body(const GemmArgs& p) {
     const int wfb0 = H_WBASE + swz2(wn * WTN + r16h, q4h), wfb1 = H_WBASE + swz2(wn * WTN + r16h, 4 + q4h);
     bf16x8_t xf[2][TM], wf[2][TN];
     const int hq0 = hq;
-    int wslot = 0, srem = (hq1 - hq) * 9 - 1;             // ring slot of the current step; steps after the current one
+    constexpr int SC = H_NT;                              // steps per cycle (two chunks x H_NT items, two items per step)
+    constexpr int HP3 = HUP ? 9 : 3;                      // halo pieces per wave and window
+    int wslot = 0, srem = (hq1 - hq) * SC - 1;            // ring slot of the current step; steps after the current one
     constexpr int NRD = TM + TN, NMF = TM * TN, NSLOT = NMF / 2;
-    static_assert(NMF % 2 == 0 && NRD <= NSLOT && B_INS + 3 <= NSLOT, "big-wave halo loop: slot schedule");
+    static_assert(NMF % 2 == 0 && NRD <= NSLOT && B_INS + HP3 <= NSLOT && H_INS <= 3 * HP3, "big-wave halo loop: slot schedule");
     // fragment read R of item IT (0..17 of the cycle) into register set G, W tile in ring slot `slot`; order: W 0, A 0..TM-1, W 1..
     auto rd = [&](auto GC, auto ITC, auto RC, int slot) {
       constexpr int g = decltype(GC)::value, it = decltype(ITC)::value, r = decltype(RC)::value;
-      constexpr int hb = it >= 9 ? 1 : 0, tap = it % 9, ky = tap / 3, kx = tap - 3 * ky;
+      constexpr int hb = it >= H_NT ? 1 : 0, tap = it % H_NT, ky = HUP ? tap / 2 : tap / 3, kx = HUP ? tap % 2 : tap % 3;
       if constexpr (r == 0 || r > TM) {
         constexpr int j = r == 0 ? 0 : r - TM;
         wf[g][j] = *reinterpret_cast<const bf16x8_t*>(smem + slot * H_WST + ((it & 1) ? wfb1 : wfb0) + j * 2048);
@@ -584,7 +593,7 @@ __device__ __forceinline__ void gemm2_body(const GemmArgs& p) {
         }(), ...);
       }(std::make_integer_sequence<int, NSLOT>{});
     };
-    auto halo3 = [&](auto KC, auto FIRST, int hb, int chunk) {   // slot KC (0..2) of a halo window whose first piece slot is FIRST
+    auto halo3 = [&](auto KC, auto FIRST, int hb, int chunk) {   // slot KC (0..HP3-1) of a halo window whose first piece slot is FIRST
       constexpr int k = decltype(KC)::value, i = decltype(FIRST)::value + k;
       if constexpr (i < H_INS) {
         if (H_PIECES % NW == 0 || i < H_INS - 1 || wave + NW * i < H_PIECES) { h_issue_h(std::integral_constant<int, i>{}, hb, chunk); return; }
@@ -602,35 +611,38 @@ __device__ __forceinline__ void gemm2_body(const GemmArgs& p) {
       item(C0{}, std::integral_constant<int, 2 * J + 1>{}, wslot, [](auto) {});
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       // B(s): tile s + 1 and every halo piece two windows old have landed
-      const bool hprev = (J == 0 || J == 1 || J == 2) ? hq > hq0 : (J >= 5 && J <= 7) ? hq + 1 < hq1 : false;
-      if (srem >= 3) { if (hprev) wait_vmcnt<2 * B_INS + 3>(); else wait_vmcnt<2 * B_INS>(); }
+      // (3x3: halo windows after B(4), B(5), B(6) -> buffer 0, after B(8), B(0), B(1) -> buffer 1, three pieces each;
+      //  phase form, 4 steps per cycle: after B(1) -> buffer 0, after B(3) -> buffer 1, the whole chunk each)
+      const bool hprev = HUP ? (J == 2 ? hq + 1 < hq1 : J == 0 ? hq > hq0 : false)
+                             : ((J == 0 || J == 1 || J == 2) ? hq > hq0 : (J >= 5 && J <= 7) ? hq + 1 < hq1 : false);
+      if (srem >= 3) { if (hprev) wait_vmcnt<2 * B_INS + HP3>(); else wait_vmcnt<2 * B_INS>(); }
       else if (srem == 2) wait_vmcnt<B_INS>();
       else wait_vmcnt<0>();
       __builtin_amdgcn_s_barrier();
       // item 1: MFMAs of item 2J + 1 (set 1), reads of the next step's first item (set 0, next W tile), this window's DMA
       const int nslot = (wslot + 1) & (H_S - 1);
       const bool wmore = srem >= H_S;
-      constexpr int nj = (J + H_S) % 9, ia = 2 * nj, ib = ia + 1;
-      const int kq = (hq + (J + H_S >= 9 ? 1 : 0)) * 64;
-      const int wdelta = wsel ? (ib % 9) * p.Cin + kq + (ib >= 9 ? 32 : 0) : (ia % 9) * p.Cin + kq + (ia >= 9 ? 32 : 0);
-      constexpr bool HWIN = J <= 1 || (J >= 4 && J <= 6) || J == 8;                 // a halo window
-      const bool hact = J <= 1 ? hq > hq0 : hq + 1 < hq1;                             // ... that has a chunk to fetch
-      constexpr int hfirst = J <= 1 ? 3 * (J + 1) : J == 8 ? 0 : 3 * (J - 4);
-      constexpr int hbuf = (J >= 4 && J <= 6) ? 0 : 1;
-      const int hchunk = J <= 1 ? 2 * hq + 1 : J == 8 ? 2 * hq + 3 : 2 * hq + 2;
-      item(C1{}, std::integral_constant<int, 2 * ((J + 1) % 9)>{}, nslot, [&](auto KC) {
+      constexpr int nj = (J + H_S) % SC, ia = 2 * nj, ib = ia + 1;
+      const int kq = (hq + (J + H_S) / SC) * 64;
+      const int wdelta = wsel ? (ib % H_NT) * p.Cin + kq + (ib >= H_NT ? 32 : 0) : (ia % H_NT) * p.Cin + kq + (ia >= H_NT ? 32 : 0);
+      constexpr bool HWIN = HUP ? (J == 1 || J == 3) : (J <= 1 || (J >= 4 && J <= 6) || J == 8);   // a halo window
+      const bool hact = (!HUP && J <= 1) ? hq > hq0 : hq + 1 < hq1;                                   // ... that has a chunk to fetch
+      constexpr int hfirst = HUP ? 0 : J <= 1 ? 3 * (J + 1) : J == 8 ? 0 : 3 * (J - 4);
+      constexpr int hbuf = HUP ? (J == 1 ? 0 : 1) : (J >= 4 && J <= 6) ? 0 : 1;
+      const int hchunk = HUP ? (J == 1 ? 2 * hq + 2 : 2 * hq + 3) : J <= 1 ? 2 * hq + 1 : J == 8 ? 2 * hq + 3 : 2 * hq + 2;
+      item(C1{}, std::integral_constant<int, 2 * ((J + 1) % SC)>{}, nslot, [&](auto KC) {
         constexpr int k = decltype(KC)::value;
-        if constexpr (HWIN && k < 3) { if (hact) halo3(KC, std::integral_constant<int, hfirst>{}, hbuf, hchunk); }
-        if constexpr (k >= 3 && k < 3 + B_INS) {
-          if (wmore && !GEMM2_DBG(1)) lds_dma16<true>(hwsrc[k - 3] + wdelta, smem + H_WBASE + wslot * H_WST + (wave + NW * (k - 3)) * 1024);
+        if constexpr (HWIN && k < HP3) { if (hact) halo3(KC, std::integral_constant<int, hfirst>{}, hbuf, hchunk); }
+        if constexpr (k >= HP3 && k < HP3 + B_INS) {
+          if (wmore && !GEMM2_DBG(1)) lds_dma16<true>(hwsrc[k - HP3] + wdelta, smem + H_WBASE + wslot * H_WST + (wave + NW * (k - HP3)) * 1024);
         }
       });
       wslot = nslot;
       --srem;
-      if constexpr (J == 8) ++hq;
+      if constexpr (J == SC - 1) ++hq;
     };
     for (;;) {
-      [&]<int... J>(std::integer_sequence<int, J...>) { (hb_step(std::integral_constant<int, J>{}), ...); }(std::make_integer_sequence<int, 9>{});
+      [&]<int... J>(std::integer_sequence<int, J...>) { (hb_step(std::integral_constant<int, J>{}), ...); }(std::make_integer_sequence<int, SC>{});
       if (hq >= hq1) break;
     }
   } else if constexpr (HALO) {

@@ -9,11 +9,28 @@ __global__ __launch_bounds__(256) void gemm2hbw_kernel(const GemmArgs p) {
   else gemm2_body<bf16_t, 256, 160, 2, 2, 2, true, 0, 8>(p);
 }
 
+// the phase form of nearest-2x upsample + conv3x3 (sdamd_conv3x3 upsample = 2; diffusion.py:148-150): grid.y = output phase
+__global__ __launch_bounds__(256) void gemm2hbwup_kernel(const GemmArgs p) {
+  if (p.Wo == 32) gemm2_body<bf16_t, 256, 160, 2, 2, 2, true, 0, 9>(p);
+  else gemm2_body<bf16_t, 256, 160, 2, 2, 2, true, 0, 10>(p);
+}
+
 static constexpr int hbw_lds(int w) { return 4 * 160 * 128 + 2 * (256 / w + 2) * (w + 16) * 64; }
 
 // `a` planned for the 128x160 tile (tiles_n, splits); takes it when the halo form would and the image rows tile 256 pixels
+// phase form: all four phases in one un-split launch, low-resolution images 32 or 16 wide
+static bool hbw_up_takes(const GemmArgs& a, int batch) {
+  extern int g_gemm_pp;
+  if ((g_gemm_pp & (2 | 8)) || !a.phase_up || batch != 4 || a.phase_base != 0 || a.ups || a.stride != 1 || a.R) return false;
+  if (a.H != a.Ho || a.Wd != a.Wo || (a.Wo != 32 && a.Wo != 16) || (a.Ho * a.Wo) % 256 != 0 || a.M % 256 != 0) return false;
+  // (one workgroup per CU: with fewer than 256 of them the 128-row kernel's 2x finer grid wins -- UNet batch 2, 32x32: 81 vs 100 us)
+  if ((long long)(a.M / 256) * ((a.N + 159) / 160) * 4 < 256) return false;
+  return a.Cin % 64 == 0 && a.Cin <= HALO_MAX_CIN && a.K == 4 * a.Cin && a.ldw == a.K && a.splits == 1;
+}
+
 bool gemm2hbw_takes(const GemmArgs& a, int batch) {
   extern int g_gemm_pp, g_gemm_debug;
+  if (a.phase_up) return hbw_up_takes(a, batch);
   if ((g_gemm_pp & 2) || !gemm2halo_width(a, batch)) return false;
   if ((a.Ho * a.Wo) % 256 != 0 || a.M % 256 != 0) return false;
   // One workgroup per CU: prologue (140 KB of DMA before the first MFMA) and epilogue are exposed, nothing else runs on the
@@ -31,6 +48,14 @@ int launch_gemm2hbw(GemmArgs& a, int batch, hipStream_t st) {
   if (sd_lds_opt_in(lds_ok, (const void*)gemm2hbw_kernel, lds) != hipSuccess)
     return sdamd_set_error(2, "gemm2hbw: cannot reserve %d bytes of LDS", lds);
   a.tiles_m = a.M / 256;
+  if (a.phase_up) {
+    static std::atomic<unsigned long long> lds_ok_up{0};
+    if (sd_lds_opt_in(lds_ok_up, (const void*)gemm2hbwup_kernel, lds) != hipSuccess)
+      return sdamd_set_error(2, "gemm2hbw: cannot reserve %d bytes of LDS", lds);
+    gemm2hbwup_kernel<<<dim3(a.tiles_m * a.tiles_n, 4, 1), 256, hbw_lds(a.Wo), st>>>(a);
+    SD_LAUNCH_CHECK("gemm2hbwup");
+    return 0;
+  }
   dim3 grid(a.tiles_m * a.tiles_n, 1, a.splits);
   gemm2hbw_kernel<<<grid, 256, hbw_lds(a.Wo), st>>>(a);
   SD_LAUNCH_CHECK("gemm2hbw");

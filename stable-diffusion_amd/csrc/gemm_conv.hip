@@ -475,7 +475,19 @@ extern "C" int sdamd_gemm_tile(int M, int N, int K, int batch, int dtype, size_t
 // kernel (gemm4.hip; + 256 when it is the 256-row big-wave kernel of gemm5.hip), else 0.
 extern "C" int sdamd_conv3x3_halo(int B, int H, int Wd, int Cin, int Cout, int stride, int pad_mode, int upsample, int dtype,
                                   size_t ws_bytes) {
-  if (g_gemm_impl == 1 || dtype != SDAMD_BF16 || upsample || pad_mode != 0 || stride != 1 || B <= 0 || H <= 0 || Wd <= 0 || Cin % 64 != 0) return 0;
+  if (g_gemm_impl == 1 || dtype != SDAMD_BF16 || upsample == 1 || pad_mode != 0 || stride != 1 || B <= 0 || H <= 0 || Wd <= 0 || Cin % 64 != 0) return 0;
+  if (upsample == 2) {   // phase form: one batched launch of the four phases (the K-split per-phase launches stay on the gathered kernel)
+    GemmArgs u = {};
+    u.M = B * H * Wd; u.N = Cout; u.K = 4 * Cin; u.ldw = u.K;
+    u.H = u.Ho = H; u.Wd = u.Wo = Wd; u.Cin = Cin; u.stride = 1; u.pad = 1; u.phase_up = 1;
+    if (ws_bytes && 4LL * ((plan_rows(u.M) + 127) / 128) * ((u.N + 159) / 160) < 256) {
+      int sp = 1;
+      if (gemm2_choose_tile(u.M, u.N, u.K, 1, g_gemm_impl, ws_bytes, &sp, 64) && sp > 1) return 0;
+    }
+    int stages = 2;
+    if (gemm2_choose_tile(u.M, u.N, u.K, 4, g_gemm_impl, ws_bytes, &u.splits, 64, &stages) != 128160 || stages != 2) return 0;
+    return gemm2hbw_takes(u, 4) ? (Wd | 0x100) : 0;
+  }
   GemmArgs a = {};
   a.M = B * H * Wd; a.N = Cout; a.K = 9 * Cin; a.ldw = a.K;
   a.H = a.Ho = H; a.Wd = a.Wo = Wd; a.Cin = Cin; a.stride = 1; a.pad = 1;

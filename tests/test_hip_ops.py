@@ -513,6 +513,35 @@ def test_conv3x3_upsample_phase_form(B, C, Cout, H, W, dup):
     assert rel_l2(from_nhwc(got), want) < (2e-3 if dup == 2 else 4e-3)
 
 
+@pytest.mark.parametrize("B,C,Cout,HW,dup", [(4, 640, 640, 32, 1), (4, 320, 640, 32, 2), (16, 704, 640, 16, 1), (16, 320, 640, 16, 2)])
+def test_conv3x3_upsample_phase_form_big_wave(B, C, Cout, HW, dup):
+    """The phase form on the halo-staged one-wave-per-SIMD kernel (gemm5.hip, low-resolution images 32 / 16 wide, all four
+    phases in one launch that fills the chip; plain and hi|lo operands, an odd number of 64-channel cycles) against the
+    reference op and against the gathered kernel it replaces (library switch bit 23).  diffusion.py:148-150."""
+    from sd_amd import engine, _lib
+    L = _lib.lib()
+    conv = torch.nn.Conv2d(C, Cout, 3, padding=1)
+    synth.load_hashed(conv, f"ops.upbw{C}.")
+    x = rnd(f"upbw.x.{C}.{HW}.{B}", (B, C, HW, HW))
+    want = conv(F.interpolate(x, scale_factor=2, mode="nearest"))
+    conv.to(DEV)
+    wp = engine.conv3x3_up_phase_w(conv, torch.bfloat16, dup)
+    xin = to_nhwc(x, torch.float32)
+    xin = ops.split_hilo(xin) if dup == 2 else xin.bfloat16()
+    ws = ops._gemm_workspace(torch.device(DEV))
+    assert L.sdamd_conv3x3_halo(B, HW, HW, dup * C, Cout, 1, 0, 2, 1, ws.numel()) == (HW | 0x100)
+    got = ops.conv3x3(xin, wp, engine.f32(conv.bias), None, 1, 0, 2, out_f32=True)
+    old = L.sdamd_set_gemm_impl(8 << 20)
+    try:
+        assert L.sdamd_conv3x3_halo(B, HW, HW, dup * C, Cout, 1, 0, 2, 1, ws.numel()) == 0
+        gathered = ops.conv3x3(xin, wp, engine.f32(conv.bias), None, 1, 0, 2, out_f32=True)
+    finally:
+        L.sdamd_set_gemm_impl(old)
+    assert tuple(got.shape) == (B, 2 * HW, 2 * HW, Cout)
+    assert rel_l2(from_nhwc(got), want) < (2e-3 if dup == 2 else 4e-3)
+    assert rel_l2(got.cpu(), gathered.cpu()) < 1e-6       # same products, another f32 summation order
+
+
 def test_conv3x3_upsample_phase_form_f32_split():
     """fp32 UNet batch 2, the 16x16 -> 32x32 upsample conv: each phase is a launch of its own with an 8-way K split."""
     from sd_amd import engine, _lib
