@@ -6,7 +6,7 @@ from sd_amd import ops, _lib
 torch.set_grad_enabled(False)
 dev = "cuda"
 g = torch.Generator(device=dev).manual_seed(0)
-variants = [int(a) for a in sys.argv[1:]] or [17, 0]   # 17 = reference tracked per tile, 0 = the default (fixed reference)
+variants = [int(a) for a in sys.argv[1:]] or [17, 0]   # 17 = reference tracked per tile, 0 = the default (fixed reference), 19 = the pipelined one-wave-per-SIMD kernel (attention2.hip; 20-24 its ablations in a -DSDAMD_ATTN_ABLATE build)
 L = _lib.lib()
 for B, H, d, S in [(16, 8, 40, 4096), (2, 8, 40, 4096), (16, 8, 40, 9216 // 4)]:
     C = H * d

@@ -6,5 +6,8 @@ g = torch.Generator(device="cuda").manual_seed(0)
 B, H, d, S = 16, 8, int(sys.argv[1]) if len(sys.argv) > 1 else 40, int(sys.argv[2]) if len(sys.argv) > 2 else 4096
 qkv = torch.randn(B, S, 3 * H * d, device="cuda", generator=g).bfloat16()
 C = H * d
+if len(sys.argv) > 3:   # library debug word (sdamd_set_gemm_impl(debug << 8)): kernel variants / timing ablations
+    from sd_amd import _lib
+    _lib.lib().sdamd_set_gemm_impl(int(sys.argv[3]) << 8)
 for _ in range(3): ops.attention(qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:], H)
 torch.cuda.synchronize()

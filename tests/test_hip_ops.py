@@ -764,6 +764,29 @@ def test_flash_attention_vae_head_full_size_and_spiky(dtype):
     assert rel_l2(got[:, rows].float().cpu(), want) < tol(dtype, 3e-6, 1e-2)
 
 
+def test_flash_attention_d40_pipelined_experiment_is_bit_equal():
+    """attention2.hip (opt-in, library debug word 19: the software-pipelined one-wave-per-SIMD d = 40 kernel, slower than
+    the default and kept as a measured experiment) computes the same function with the same roundings as the default
+    kernel -- bit-equal outputs on ordinary data, at ragged tile counts (8, 9, 10, 11, 13 tiles of 64 keys), and on rows that
+    overflow the fixed reference (its whole-workgroup re-run through the tracked path).  attention.py:46-68."""
+    from sd_amd import _lib
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(11)
+    H, d = 2, 40
+    C = H * d
+    for S, amp in ((512, 1.0), (576, 1.0), (640, 1.0), (704, 1.0), (832, 1.0), (1024, 40.0)):
+        qkv = torch.randn(2, S, 3 * C, generator=g)
+        if amp != 1.0: qkv[:, S // 2:, C:2 * C] *= amp          # late keys far above the first tile's reference
+        dv = qkv.bfloat16().to(DEV)
+        base = ops.attention(dv[..., :C], dv[..., C:2 * C], dv[..., 2 * C:], H)
+        old = L.sdamd_set_gemm_impl(19 << 8)
+        try:
+            got = ops.attention(dv[..., :C], dv[..., C:2 * C], dv[..., 2 * C:], H)
+        finally:
+            L.sdamd_set_gemm_impl(old)
+        assert torch.isfinite(got.float()).all() and torch.equal(got, base), (S, amp)
+
+
 @pytest.mark.parametrize("impl", [0, 1, 2, 3])
 def test_f32_modes_against_float64(impl):
     """include/sdamd.h sdamd_set_f32_mode: the default fp32 path forms each product from three-term bf16 splits of both
