@@ -69,6 +69,8 @@ def kernel_symbol(kind):
         wg = {"128x320": "2, 4, 2", "128x160": "2, 2, 2", "64x160": "2, 2, 2", "256x256": "2, 4, 2", "256x320": "4, 2, 2"}.get(parts[2])
         if wg is not None:      # LDS-DMA family (gemm2.hip); last argument: 1 = residual-prefetch, 2 = GeGLU-only, 3 = fused LayerNorm epilogue
             epi = 1 if 'rp' in parts[3:] else 2 if 'geglu' in parts[3:] else 3 if 'ln' in parts[3:] else 0
+            if 'hbwup' in parts[3:]:
+                return "gemm2hbwup_kernel"                                            # ... its phase form (upsample + conv3x3)
             if 'hbw' in parts[3:]:
                 return "gemm2hbw_kernel"                                              # 256-row big-wave halo conv3x3 (gemm5.hip)
             if 'halo' in parts[3:]:

@@ -185,7 +185,8 @@ int sdamd_split3_weights(const float* w, void* planes, long long rows, int K, in
 int sdamd_gemm_tile(int M, int N, int K, int batch, int dtype, size_t ws_bytes, int act);
 /* host-only, as sdamd_gemm_tile: the image width (64 / 32 / 16) when sdamd_conv3x3 runs this problem on a halo-staged
  * kernel (stride 1, pad 1, bf16, whole image rows per 128-pixel tile: the resblock convs of diffusion.py:9,13), plus 256
- * when that is the 256-row one-wave-per-SIMD kernel (Cin >= 1280, or >= 640 on 16-wide images), else 0 */
+ * when that is the 256-row one-wave-per-SIMD kernel (Cin >= 1280, or >= 640 on 16-wide images; + 512 more for its phase
+ * form, upsample == 2), else 0 */
 int sdamd_conv3x3_halo(int B, int H, int Wd, int Cin, int Cout, int stride, int pad_mode, int upsample, int dtype,
                        size_t ws_bytes);
 /* 1 when sdamd_gemm can apply `act` in its epilogue for this dtype / N (GEGLU: see above) */

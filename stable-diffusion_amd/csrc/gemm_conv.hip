@@ -486,7 +486,7 @@ extern "C" int sdamd_conv3x3_halo(int B, int H, int Wd, int Cin, int Cout, int s
     }
     int stages = 2;
     if (gemm2_choose_tile(u.M, u.N, u.K, 4, g_gemm_impl, ws_bytes, &u.splits, 64, &stages) != 128160 || stages != 2) return 0;
-    return gemm2hbw_takes(u, 4) ? (Wd | 0x100) : 0;
+    return gemm2hbw_takes(u, 4) ? (Wd | 0x300) : 0;   // bits 8 + 9: the big-wave kernel's phase form (gemm2hbwup_kernel)
   }
   GemmArgs a = {};
   a.M = B * H * Wd; a.N = Cout; a.K = 9 * Cin; a.ldw = a.K;

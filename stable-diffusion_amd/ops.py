@@ -622,7 +622,7 @@ def geglu_pack(t):
 
 
 def _halo_tag(h):
-    return "_hbw" if h & 0x100 else "_halo" if h else ""
+    return "_hbwup" if h & 0x200 else "_hbw" if h & 0x100 else "_halo" if h else ""
 
 
 def conv3x3(x, w, bias, residual=None, stride=1, pad_mode=0, upsample=False, act=ACT_NONE, out_f32=False, flops_cin=None,

@@ -529,7 +529,7 @@ def test_conv3x3_upsample_phase_form_big_wave(B, C, Cout, HW, dup):
     xin = to_nhwc(x, torch.float32)
     xin = ops.split_hilo(xin) if dup == 2 else xin.bfloat16()
     ws = ops._gemm_workspace(torch.device(DEV))
-    assert L.sdamd_conv3x3_halo(B, HW, HW, dup * C, Cout, 1, 0, 2, 1, ws.numel()) == (HW | 0x100)
+    assert L.sdamd_conv3x3_halo(B, HW, HW, dup * C, Cout, 1, 0, 2, 1, ws.numel()) == (HW | 0x300)
     got = ops.conv3x3(xin, wp, engine.f32(conv.bias), None, 1, 0, 2, out_f32=True)
     old = L.sdamd_set_gemm_impl(8 << 20)
     try:

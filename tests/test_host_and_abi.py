@@ -137,6 +137,7 @@ def test_bench_labels_map_to_kernel_symbols():
     assert ks("conv3x3_bf16_128x160_halo") == "gemm2halo_kernel<0>" and ks("conv3x3_bf16_128x160_rp_halo") == "gemm2halo_kernel<1>"
     assert ks("conv3x3_bf16_128x160_splitk2_halo") == "gemm2halo_kernel<0>"
     assert ks("conv3x3_bf16_128x160_hbw") == ks("conv3x3_bf16_128x160_rp_hbw") == "gemm2hbw_kernel"
+    assert ks("conv3x3_bf16_128x160_hbwup") == "gemm2hbwup_kernel"
     assert ks("gemm_bf16_128x320_ln") == "gemm2_kernel<unsigned short, 128, 320, 2, 4, 2, false, 3>"
     assert ks("gemm_f32_128x160") == "gemm2_kernel<float, 128, 160, 2, 2, 2, false, 0>"
     assert ks("gemm_f32_64x64") == "gemm_kernel<float, 64, 64, false>"
