@@ -107,6 +107,7 @@ def parse_args():
     ap.add_argument("--skip-fp32-latency", action="store_true")
     ap.add_argument("--skip-predrawn", action="store_true")
     ap.add_argument("--deterministic-plan", action="store_true", help="generate(deterministic_plan=True): bit-exact shard invariance, slower (rehearsal)")
+    ap.add_argument("--gemm-impl", type=int, default=0, help="library switch word for same-box A/B runs (sdamd_set_gemm_impl; e.g. 8388608 = halo-staged convs off); marks the line a rehearsal")
     return ap.parse_args()
 
 
@@ -325,7 +326,10 @@ def run(args):
     else:                                          # weak scaling: every GPU its own images
         batch = cfg["batch"] if args.batch is None else args.batch
         first, total = rank * batch, world * batch
-    standard = args.batch is None and args.denoise_steps == 50 and not args.deterministic_plan
+    standard = args.batch is None and args.denoise_steps == 50 and not args.deterministic_plan and not args.gemm_impl
+    if args.gemm_impl:
+        from sd_amd import _lib
+        _lib.lib().sdamd_set_gemm_impl(args.gemm_impl)
     if cfg["res"] != 512:                          # the reference's resolution is four module constants (pipeline.py:9-13)
         pipeline.WIDTH = pipeline.HEIGHT = cfg["res"]
         pipeline.LATENTS_WIDTH = pipeline.LATENT_HEIGHT = cfg["res"] // 8
