@@ -168,7 +168,7 @@ __device__ __forceinline__ void attn_body(const AttnArgs& p) {
     }
   };
   for (int c = t; c < 2 * BKV * (KC - DC + VC - DC); c += 256) {   // constant pad chunks of both stages
-    constexpr int NPAD = KC - DC + VC - DC;
+    constexpr int NPAD = KC - DC + VC - DC > 0 ? KC - DC + VC - DC : 1;   // (no pads at all: the loop does not run)
     const int srow = c / NPAD, pc = c - srow * NPAD;               // srow = stage * BKV + row
     char* base = smem + (srow / BKV) * STAGE;
     const int row = srow % BKV;
