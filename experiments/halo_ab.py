@@ -19,8 +19,8 @@ def t(fn, n):
         e.record(); torch.cuda.synchronize(); ts.append(s.elapsed_time(e) / n)
     return sorted(ts)[2]
 shapes = [(16, 64, 64, 320, 320), (16, 64, 64, 640, 320), (16, 64, 64, 960, 320), (16, 32, 32, 640, 640), (16, 32, 32, 1280, 640), (16, 32, 32, 1920, 640),
-          (16, 16, 16, 1280, 1280), (16, 16, 16, 2560, 1280), (2, 64, 64, 320, 320), (2, 32, 32, 640, 640), (2, 16, 16, 1280, 1280), (1, 64, 64, 320, 320)]
-if len(sys.argv) > 1: shapes = shapes[:1] + shapes[3:4] + shapes[6:7] + shapes[8:]
+          (16, 16, 16, 1280, 1280), (16, 16, 16, 2560, 1280), (2, 64, 64, 320, 320), (2, 32, 32, 640, 640), (2, 16, 16, 1280, 1280), (1, 64, 64, 320, 320), (16, 8, 8, 1280, 1280), (16, 8, 8, 2560, 1280)]
+if len(sys.argv) > 1: shapes = shapes[:1] + shapes[3:4] + shapes[6:7] + shapes[8:] if sys.argv[1] == 'q' else shapes[-2:]
 for B, H, W, Cin, Cout in shapes:
     NR = max(2, min(8, int(600e6 / (B * H * W * Cin * 2))))
     xs = [rnd(B, H, W, Cin).bfloat16() for _ in range(NR)]

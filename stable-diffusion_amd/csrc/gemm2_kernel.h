@@ -86,12 +86,13 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
 // PP: 0 = the one-barrier-per-K-tile ring of the header; 1, 2 = the "ping-pong" main loop (see GEMM2 PING-PONG below);
 //     3, 4, 5 = the halo-staged conv3x3 loop for images 64, 32, 16 pixels wide (see GEMM2 HALO below);
 //     6, 7, 8 = the same on a 256-row tile with one wave per SIMD and a software-pipelined step (GEMM2 HALO BIG-WAVE);
-//     9, 10 = the big-wave loop on the phase-decomposed upsample conv (p.phase_up; low-resolution images 32, 16 wide).
+//     9, 10 = the big-wave loop on the phase-decomposed upsample conv (p.phase_up; low-resolution images 32, 16 wide);
+//     11 = the big-wave loop on 8 x 8 images (a 256-row tile = four whole images; split-K launches only).
 template <typename T, int BM, int BN, int WGM, int WGN, int STAGES, bool CONV, int EPI, int PP>
 __device__ __forceinline__ void gemm2_body(const GemmArgs& p) {
   constexpr bool PPL = PP == 1 || PP == 2;
-  constexpr int HALO_W = (PP == 3 || PP == 6) ? 64 : (PP == 4 || PP == 7 || PP == 9) ? 32 : (PP == 5 || PP == 8 || PP == 10) ? 16 : 0;
-  constexpr bool HUP = PP >= 9;            // big-wave halo loop on the phase form of upsample + conv3x3: 4 taps (2 x 2) per phase
+  constexpr int HALO_W = (PP == 3 || PP == 6) ? 64 : (PP == 4 || PP == 7 || PP == 9) ? 32 : (PP == 5 || PP == 8 || PP == 10) ? 16 : PP == 11 ? 8 : 0;
+  constexpr bool HUP = PP == 9 || PP == 10;            // big-wave halo loop on the phase form of upsample + conv3x3: 4 taps (2 x 2) per phase
   constexpr int H_NT = HUP ? 4 : 9;        // filter taps = items per 32-channel chunk = steps per cycle of two chunks
   constexpr bool HALO = HALO_W != 0;
   constexpr bool ASM_DMA = PP >= 6;        // LDS-DMA from inline assembly (lds_dma16); measured on every other kernel: bit-equal results, no gain (+0.0 ... +0.2 % per UNet step)
@@ -411,8 +412,11 @@ __device__ __forceinline__ void gemm2_body(const GemmArgs& p) {
   // per wave and step instead of 9.  LDS: W ring 2 x 20 KB + halo 2 x <= 20 KB = 80 KB, two workgroups per CU.
   // The K order (chunk-major) differs from the gathered form's (tap-major): same products, another f32 summation order.
   constexpr int H_WD = HALO ? HALO_W : BM;
-  constexpr int H_HP = H_WD + 16, H_HR = BM / H_WD + 2;                  // halo row pitch (pixels) and rows
+  // 8 x 8 images (H8): a tile is BM / 64 whole images, each with its own 10 x 10 halo at a row pitch of 16 pixels
+  constexpr bool H8 = HALO_W == 8;
+  constexpr int H_HP = H8 ? 16 : H_WD + 16, H_HR = H8 ? 10 * (BM / 64) : BM / H_WD + 2;   // halo row pitch (pixels) and rows
   constexpr int H_BYTES = H_HR * H_HP * 64, H_PIECES = H_BYTES / 1024, H_INS = (H_PIECES + NW - 1) / NW;
+  constexpr int HP3 = HUP ? 9 : H8 ? 4 : 3;                              // big-wave loop: halo pieces per wave and DMA window
   constexpr int H_WST = BN * 128;                                        // one W ring stage
   constexpr int H_S = HBW ? 4 : 2;                                       // W ring depth
   constexpr int H_BASE = HBW ? 0 : 2 * H_WST, H_WBASE = HBW ? 2 * H_BYTES : 0;   // halo buffers / W ring inside smem
@@ -435,12 +439,12 @@ __device__ __forceinline__ void gemm2_body(const GemmArgs& p) {
     lds_dma16<ASM_DMA>(hsrc[i] + chunk * 32, smem + H_BASE + hb * H_BYTES + (wave + NW * i) * 1024);
   };
   if constexpr (HALO) {
-    static_assert(CONV && !F32 && !EMU && NW == 4 && WGM == 2 && (BM == 128 || HBW) && STAGES == 2 && B_PIECES % NW == 0 && BM % H_WD == 0 && H_WD % 16 == 0,
+    static_assert(CONV && !F32 && !EMU && NW == 4 && WGM == 2 && (BM == 128 || HBW) && STAGES == 2 && B_PIECES % NW == 0 && BM % H_WD == 0 && (H_WD % 16 == 0 || (H8 && HBW)),
                   "halo loop: bf16 conv on the 4-wave 128-row tile");
     static_assert(H_BYTES % 1024 == 0 && (HBW || (H_INS == 5 && H_BASE + 2 * H_BYTES <= 80 * 1024)), "halo loop: piece schedule / LDS budget (two workgroups per CU)");
     static_assert(!HBW || EPI == 0, "big-wave halo loop: the counted waits assume no other vector-memory loads in flight (no residual prefetch)");
     static_assert(!HUP || (EPI == 0 && H_NT >= H_S), "phase form: EPI 0 only (out_row), and a launch has >= H_S steps");
-    static_assert(!HBW || (BM == 256 && H_INS <= 9 && 2 * H_BYTES + H_S * H_WST <= 160 * 1024 && B_INS == 5), "big-wave halo loop: piece schedule / LDS budget");
+    static_assert(!HBW || (BM == 256 && H_INS <= 3 * HP3 && 2 * H_BYTES + H_S * H_WST <= 160 * 1024 && B_INS == 5), "big-wave halo loop: piece schedule / LDS budget");
     const int hw = p.Ho * p.Wo;
     const int n_img = m0 / hw, y0 = (m0 - n_img * hw) / HALO_W;
 #pragma unroll
@@ -449,9 +453,10 @@ __device__ __forceinline__ void gemm2_body(const GemmArgs& p) {
       const int slot = g * 16 + (lane >> 2);                            // pixel slot of the halo buffer
       const int hy = slot / H_HP, hx = slot - hy * H_HP;
       const int sc = (lane & 3) ^ ((slot >> 2) & 3);                    // source chunk landing in this lane's position
-      const int y = y0 - 1 + hy, x = hx - 1;
+      const int img = H8 ? hy / 10 : 0;                                 // (H8: image of the tile, row inside its 10-row halo)
+      const int y = H8 ? hy - 10 * img - 1 : y0 - 1 + hy, x = hx - 1;
       const bool in = (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)HALO_W;
-      hsrc[i] = (in ? A + ((long long)(n_img * p.H + y) * HALO_W + x) * p.Cin : reinterpret_cast<const T*>(g_zero_page)) + sc * 8;
+      hsrc[i] = (in ? A + ((long long)((n_img + img) * p.H + y) * HALO_W + x) * p.Cin : reinterpret_cast<const T*>(g_zero_page)) + sc * 8;
     }
 #pragma unroll
     for (int i = 0; i < B_INS; ++i) {
@@ -463,7 +468,7 @@ __device__ __forceinline__ void gemm2_body(const GemmArgs& p) {
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       const int ml = wm * WTM + i * 16 + (lane & 15);
-      const int yl = ml / HALO_W, xl = ml - yl * HALO_W;
+      const int yl = H8 ? 10 * (ml >> 6) + ((ml >> 3) & 7) : ml / HALO_W, xl = ml - (ml / HALO_W) * HALO_W;   // halo row of the pixel
 #pragma unroll
       for (int kx = 0; kx < 3; ++kx) {
         // (phase form: tap (dy, dx) of phase (py, px) reads input pixel (y - 1 + py + dy, x - 1 + px + dx): the 3x3 form's
@@ -560,7 +565,6 @@ __device__ __forceinline__ void gemm2_body(const GemmArgs& p) {
     bf16x8_t xf[2][TM], wf[2][TN];
     const int hq0 = hq;
     constexpr int SC = H_NT;                              // steps per cycle (two chunks x H_NT items, two items per step)
-    constexpr int HP3 = HUP ? 9 : 3;                      // halo pieces per wave and window
     int wslot = 0, srem = (hq1 - hq) * SC - 1;            // ring slot of the current step; steps after the current one
     constexpr int NRD = TM + TN, NMF = TM * TN, NSLOT = NMF / 2;
     static_assert(NMF % 2 == 0 && NRD <= NSLOT && B_INS + HP3 <= NSLOT && H_INS <= 3 * HP3, "big-wave halo loop: slot schedule");
@@ -627,7 +631,7 @@ __device__ __forceinline__ void gemm2_body(const GemmArgs& p) {
       const int wdelta = wsel ? (ib % H_NT) * p.Cin + kq + (ib >= H_NT ? 32 : 0) : (ia % H_NT) * p.Cin + kq + (ia >= H_NT ? 32 : 0);
       constexpr bool HWIN = HUP ? (J == 1 || J == 3) : (J <= 1 || (J >= 4 && J <= 6) || J == 8);   // a halo window
       const bool hact = (!HUP && J <= 1) ? hq > hq0 : hq + 1 < hq1;                                   // ... that has a chunk to fetch
-      constexpr int hfirst = HUP ? 0 : J <= 1 ? 3 * (J + 1) : J == 8 ? 0 : 3 * (J - 4);
+      constexpr int hfirst = HUP ? 0 : J <= 1 ? HP3 * (J + 1) : J == 8 ? 0 : HP3 * (J - 4);
       constexpr int hbuf = HUP ? (J == 1 ? 0 : 1) : (J >= 4 && J <= 6) ? 0 : 1;
       const int hchunk = HUP ? (J == 1 ? 2 * hq + 2 : 2 * hq + 3) : J <= 1 ? 2 * hq + 1 : J == 8 ? 2 * hq + 3 : 2 * hq + 2;
       item(C1{}, std::integral_constant<int, 2 * ((J + 1) % SC)>{}, nslot, [&](auto KC) {

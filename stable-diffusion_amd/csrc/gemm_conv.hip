@@ -493,6 +493,7 @@ extern "C" int sdamd_conv3x3_halo(int B, int H, int Wd, int Cin, int Cout, int s
   a.H = a.Ho = H; a.Wd = a.Wo = Wd; a.Cin = Cin; a.stride = 1; a.pad = 1;
   int stages = 2;
   if (gemm2_choose_tile(a.M, a.N, a.K, 1, g_gemm_impl, ws_bytes, &a.splits, 64, &stages) != 128160 || stages != 2) return 0;
+  if (Wd == 8) return gemm2hbw_takes(a, 1) ? (8 | 0x100) : 0;   // 8 x 8 images: the big-wave kernel only
   const int w = gemm2halo_width(a, 1);
   return w && gemm2hbw_takes(a, 1) ? w | 0x100 : w;   // bit 8: the 256-row big-wave kernel (gemm5.hip)
 }

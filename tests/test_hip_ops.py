@@ -477,6 +477,39 @@ def test_conv3x3_halo_staged(mode, B, Cin, Cout, HW, split, big, form, monkeypat
         assert torch.allclose(st.reshape(-1, Cout, 2)[..., 0].cpu(), rows.sum(1).cpu(), rtol=1e-4, atol=1e-3)
 
 
+@pytest.mark.parametrize("mode,B,Cin,Cout,res", [(0, 16, 1280, 1280, True), (0, 16, 2560, 1280, False), (3, 4, 384, 160, True), (3, 8, 448, 480, False)])
+def test_conv3x3_halo_big_wave_8x8_images(mode, B, Cin, Cout, res):
+    """The big-wave halo kernel on 8 x 8 images (gemm5.hip: a 256-row tile = four whole images, each with its own halo;
+    K-split launches only, the splits need not divide the 64-channel cycles evenly: 20 over 8, 7 over 3) against float64 and
+    the gathered kernel (library switch bit 21).  The planner's own 8-way split at the UNet's 8x8-level shapes (mode 0)
+    and a forced 3-way split.  diffusion.py:9,13."""
+    from sd_amd import _lib
+    L = _lib.lib()
+    x = q(rnd(f"h8.x.{Cin}.{B}", (B, Cin, 8, 8)), torch.bfloat16)
+    w = q(rnd(f"h8.w.{Cin}.{Cout}", (Cout, Cin, 3, 3), 1.0 / math.sqrt(9 * Cin)), torch.bfloat16)
+    b = rnd(f"h8.b.{Cout}", (Cout,))
+    want = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+    kw = dict(out_f32=True)
+    if res:
+        r = rnd(f"h8.r.{Cout}.{B}", tuple(want.shape))
+        want = want + r
+        kw["residual"] = to_nhwc(r, torch.float32)
+    wp = w.permute(0, 2, 3, 1).reshape(Cout, -1).contiguous().bfloat16().to(DEV)
+    xn = to_nhwc(x, torch.bfloat16)
+    ws = ops._gemm_workspace(torch.device(DEV))
+    old = L.sdamd_set_gemm_impl(mode)
+    try:
+        assert L.sdamd_conv3x3_halo(B, 8, 8, Cin, Cout, 1, 0, 0, 1, ws.numel()) == (8 | 0x100)
+        got = ops.conv3x3(xn, wp, b.to(DEV), **kw)
+        L.sdamd_set_gemm_impl(mode | (2 << 20))
+        assert L.sdamd_conv3x3_halo(B, 8, 8, Cin, Cout, 1, 0, 0, 1, ws.numel()) == 0
+        gathered = ops.conv3x3(xn, wp, b.to(DEV), **kw)
+    finally:
+        L.sdamd_set_gemm_impl(old)
+    assert rel_l2(from_nhwc(got), want.float()) < 2e-6
+    assert rel_l2(got.cpu(), gathered.cpu()) < 1e-6
+
+
 def test_conv3x3_long_k_auto_split():
     """The 8x8-level UNet conv (M = 128 at UNet batch 2, K = 9*1280): the planner's own choice there is the 128x160 tile
     with an 8-way K split; bf16 operands, f32 residual and output."""
