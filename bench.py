@@ -66,7 +66,7 @@ def kernel_symbol(kind):
         bm, bn = parts[2].split("x")
         conv = "true" if parts[0] == "conv3x3" else "false"
         t = "unsigned short" if parts[1] == "bf16" else "float"
-        wg = {"128x320": "2, 4, 2", "128x160": "2, 2, 2", "64x160": "2, 2, 2", "256x256": "2, 4, 2", "256x320": "4, 2, 2"}.get(parts[2])
+        wg = {"128x320": "2, 4, 2", "128x160": "2, 2, 2", "64x160": "2, 2, 2", "256x256": "2, 4, 2", "256x320": "4, 2, 2", "256x128": "4, 2, 2"}.get(parts[2])
         if wg is not None:      # LDS-DMA family (gemm2.hip); last argument: 1 = residual-prefetch, 2 = GeGLU-only, 3 = fused LayerNorm epilogue
             epi = 1 if 'rp' in parts[3:] else 2 if 'geglu' in parts[3:] else 3 if 'ln' in parts[3:] else 0
             if 'hbwup' in parts[3:]:

@@ -205,6 +205,9 @@ int gemm2_choose_tile(int M, int N, int K, int batch, int mode, size_t ws_bytes,
     return 0;
   }
   if (N % 256 == 0 && blocks(256, 256) >= 192) return 256256;
+  // 128-wide outputs (the VAE's 512 x 512 level: decoder.py:117-122, 2 M rows): an 8-wave 256x128 tile instead of the
+  // register-staged 128x128 kernel (551 TF on those convs)
+  if (bke == 64 && N % 128 == 0 && blocks(256, 128) >= 256) return 256128;
   return 0;
 }
 
@@ -256,6 +259,9 @@ static int launch_gemm2_t(GemmArgs& a, int batch, bool conv, int mode, hipStream
       return conv ? launch2<T, 64, 160, 2, 2, 2, true>(a, batch, st) : launch2<T, 64, 160, 2, 2, 2, false>(a, batch, st);
     case 128320: return conv ? launch2<T, 128, 320, 2, 4, 2, true>(a, batch, st) : launch2<T, 128, 320, 2, 4, 2, false>(a, batch, st);
     case 256256: return conv ? launch2<T, 256, 256, 2, 4, 2, true>(a, batch, st) : launch2<T, 256, 256, 2, 4, 2, false>(a, batch, st);
+    case 256128:
+      if constexpr (sizeof(T) == 2) return conv ? launch2<T, 256, 128, 4, 2, 2, true>(a, batch, st) : launch2<T, 256, 128, 4, 2, 2, false>(a, batch, st);
+      else return -1;
     case 256320:
       if constexpr (sizeof(T) == 2) return conv ? launch2<T, 256, 320, 4, 2, 2, true>(a, batch, st) : launch2<T, 256, 320, 4, 2, 2, false>(a, batch, st);
       else return -1;

@@ -447,7 +447,7 @@ def gemm_hilo_fused(M, N, K, dtype):
     if dtype != torch.bfloat16 or not gemm_supports_act(ACT_GEGLU, dtype, 256):    # 4-wave kernels forced
         return False
     tile = _lib.lib().sdamd_gemm_tile(M, N, K, 1, _code(dtype), GEMM_WS_BYTES * max(1, PLAN_SAMPLES), 0) % 1000000
-    return tile in (64160, 128160, 128320, 256256, 256320)      # the LDS-DMA tiles (gemm2.hip); the register-staged ones have no such epilogue
+    return tile in (64160, 128160, 128320, 256256, 256320, 256128)      # the LDS-DMA tiles (gemm2.hip); the register-staged ones have no such epilogue
 
 
 def gemm(a, w, bias=None, residual=None, act=ACT_NONE, out_f32=False, out_hilo=False, flops_k=None, want_stats=False, out=None):
