@@ -25,7 +25,9 @@ static bool hbw_up_takes(const GemmArgs& a, int batch) {
   if ((g_gemm_pp & (2 | 8)) || !a.phase_up || batch != 4 || a.phase_base != 0 || a.ups || a.stride != 1 || a.R) return false;
   if (a.H != a.Ho || a.Wd != a.Wo || (a.Wo != 32 && a.Wo != 16) || (a.Ho * a.Wo) % 256 != 0 || a.M % 256 != 0) return false;
   // (one workgroup per CU: with fewer than 256 of them the 128-row kernel's 2x finer grid wins -- UNet batch 2, 32x32: 81 vs 100 us)
-  if ((long long)(a.M / 256) * ((a.N + 159) / 160) * 4 < 256) return false;
+  // (deterministic plans size that grid from one sample's rows, like every other planner: this form sums K chunk-major, the
+  //  gathered phase kernel tap-major, so the choice must not depend on how many samples share the batch)
+  if ((long long)(plan_rows(a.M) / 256) * ((a.N + 159) / 160) * 4 < 256) return false;
   return a.Cin % 64 == 0 && a.Cin <= HALO_MAX_CIN && a.K == 4 * a.Cin && a.ldw == a.K && a.splits == 1;
 }
 
@@ -35,7 +37,8 @@ static bool hbw_up_takes(const GemmArgs& a, int batch) {
 static bool hbw8_takes(const GemmArgs& a, int batch) {
   extern int g_gemm_pp;
   if ((g_gemm_pp & (2 | 8)) || batch != 1 || a.phase_up || a.ups || a.stride != 1 || a.pad != 1) return false;
-  if (a.H != 8 || a.Wd != 8 || a.Ho != 8 || a.Wo != 8 || a.M % 256 != 0) return false;
+  // (plan_rows: a deterministic plan decides from one sample's rows -- two 8x8 maps, never four -- so it keeps the gathered kernel)
+  if (a.H != 8 || a.Wd != 8 || a.Ho != 8 || a.Wo != 8 || a.M % 256 != 0 || plan_rows(a.M) % 256 != 0) return false;
   if (a.Cin % 64 != 0 || a.Cin > HALO_MAX_CIN || a.K != 9 * a.Cin || a.ldw != a.K) return false;
   // (measured per launch against the gathered kernel with its 8-way split: Cin 1280 56.2 -> 55.4 us, Cin 2560 90.0 -> 84.7 us --
   //  prologue, partial-sum epilogue and the reduce launch dominate these 18 ... 45-step loops; debug word 25 switches it off)
