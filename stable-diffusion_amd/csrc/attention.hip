@@ -6,6 +6,7 @@ template <typename T, int D, bool TRACK = false>
 __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs p) { attn_body<T, D, TRACK>(p); }
 
 int launch_attn40p(const AttnArgs& a, int B, hipStream_t st);   // attention2.hip
+int launch_xattn(const AttnArgs& a, int B, int d, hipStream_t st);   // attention3.hip
 
 template <typename T, int D, bool TRACK = false>
 static int launch_attn(const AttnArgs& a, int B, hipStream_t st) {
@@ -525,6 +526,9 @@ extern "C" int sdamd_attention(const void* q, const void* k, const void* v, void
   // Experiment, off by default (debug word 19): the software-pipelined one-wave-per-SIMD d = 40 kernel of attention2.hip --
   // bit-equal to the kernel below and SLOWER (B16 S4096: 589 vs 478 us; DESIGN.md section 4 has its ablations).
   if (d == 40 && dtype == SDAMD_BF16 && !causal && Skv % 64 == 0 && Skv >= 8 * 64 && a.debug >= 19 && a.debug <= 24) return launch_attn40p(a, B, st);
+  // Short key sequences (the 77-token cross attention): K / V staged once per workgroup, attention3.hip.  Debug word 26
+  // keeps the generic kernel (A/B, and the tests compare the two).
+  if (dtype == SDAMD_BF16 && !causal && Skv <= 96 && (d == 40 || d == 80 || d == 160) && a.debug != 26) return launch_xattn(a, B, d, st);
   { extern int g_f32_emu;
     if (dtype == SDAMD_F32 && g_f32_emu) {   // sdamd_set_f32_mode: f32 attention on the bf16 matrix pipe (the 512-wide VAE head keeps the f32 MFMA)
       if (d == 40) return launch_attn_f32x3<40>(a, B, st);

@@ -778,6 +778,35 @@ def test_flash_attention_d40_fixed_reference_fast_path_and_its_fallback():
             assert rel_l2(got.float().cpu(), tracked.float().cpu()) < 3e-2
 
 
+@pytest.mark.parametrize("d,B,Sq,Skv", [(40, 16, 3000, 77), (80, 16, 1024, 77), (160, 16, 256, 77), (160, 2, 64, 77),
+                                         (40, 16, 2048, 96), (40, 2, 300, 1), (80, 2, 200, 64), (40, 3, 130, 33)])
+def test_flash_attention_short_kv_stationary_kernel(d, B, Sq, Skv):
+    """attention3.hip: the cross attention's keys (<= 96) staged once per workgroup, each wave walking over 32-query
+    blocks (several 128-query tiles per workgroup at the big grids: Sq 3000 -> 3 tiles each, ragged last tile).  bf16
+    only.  Against the CPU oracle on two slices of the queries, and against the generic flash kernel (debug word 26
+    keeps it) -- same function, P rounded at another softmax reference; K / V as strided views of one fused projection."""
+    from sd_amd import _lib
+    L = _lib.lib()
+    H = 8
+    C = H * d
+    qq = q(rnd(f"xatt.q.{d}.{Sq}", (B, Sq, C), 1.5), torch.bfloat16)
+    kv = q(rnd(f"xatt.kv.{d}.{Skv}", (B, Skv, 2 * C), 1.2), torch.bfloat16)
+    if Skv > 40:
+        kv[:, 40, :C] *= 4.0                                     # one dominant key
+    dq, dkv = qq.to(torch.bfloat16).to(DEV), kv.to(torch.bfloat16).to(DEV)
+    got = ops.attention(dq, dkv[..., :C], dkv[..., C:], H)
+    try:
+        L.sdamd_set_gemm_impl(26 << 8)
+        generic = ops.attention(dq, dkv[..., :C], dkv[..., C:], H)
+    finally:
+        L.sdamd_set_gemm_impl(0)
+    assert torch.isfinite(got.float()).all()
+    assert rel_l2(got.float().cpu(), generic.float().cpu()) < 1e-2
+    for b, rows in ((0, slice(0, min(Sq, 160))), (B - 1, slice(max(0, Sq - 200), Sq))):
+        want = O.attention_core(qq[b:b + 1, rows], kv[b:b + 1, :, :C], kv[b:b + 1, :, C:], H)
+        assert rel_l2(got[b:b + 1, rows].float().cpu(), want) < 1e-2
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_flash_attention_vae_head_full_size_and_spiky(dtype):
     """decoder.py:39-70 at its real size (one head of 512, S = 4096 = the 64x64 map of a 512^2 image): strided views of
