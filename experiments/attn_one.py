@@ -9,5 +9,8 @@ C = H * d
 if len(sys.argv) > 3:   # library debug word (sdamd_set_gemm_impl(debug << 8)): kernel variants / timing ablations
     from sd_amd import _lib
     _lib.lib().sdamd_set_gemm_impl(int(sys.argv[3]) << 8)
-for _ in range(3): ops.attention(qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:], H)
+Skv = int(sys.argv[4]) if len(sys.argv) > 4 else S     # fewer keys than queries: cross attention (K|V from their own tensor)
+kv = qkv[:, :Skv, C:].contiguous()
+q = qkv[..., :C].contiguous() if len(sys.argv) > 4 else qkv[..., :C]   # (the cross attention's Q is a projection of its own)
+for _ in range(3): ops.attention(q, kv[..., :C], kv[..., C:], H)
 torch.cuda.synchronize()
