@@ -121,6 +121,25 @@ __device__ __forceinline__ float gelu_erf_f(float x) {
   const float hx = 0.5f * x;
   return __builtin_fmaf(__builtin_fabsf(hx), y, hx);
 }
+// The same GELU where the result is rounded to bf16 right away (the fused GeGLU epilogue of the bf16 GEMM): erf(x / sqrt 2)
+// = x Q(x^2) on |x| <= 4.4 (clamped: 1 - erf(4.4 / sqrt 2) = 1.1e-5), Q of degree 8 fitted to a maximum error of 3.4e-5 in
+// erf = 7.4e-5 in the GELU at worst (x ~ 4), 1/50 of a bf16 rounding step there.  No v_rcp / v_exp (7.7 cycles each) and the
+// Horner chain packs two values per v_pk_fma_f32: the epilogue's math is what a GeGLU tile waits for after its K loop.
+__device__ __forceinline__ float gelu_erf_bf16out_f(float x) {
+  const float xc = __builtin_fminf(__builtin_fmaxf(x, -4.4f), 4.4f);
+  const float u = xc * xc;
+  float q = __builtin_fmaf(8.874779384e-11f, u, -8.991754896e-09f);
+  q = __builtin_fmaf(q, u, 4.008112171e-07f);
+  q = __builtin_fmaf(q, u, -1.045191675e-05f);
+  q = __builtin_fmaf(q, u, 1.796257420e-04f);
+  q = __builtin_fmaf(q, u, -2.180628711e-03f);
+  q = __builtin_fmaf(q, u, 1.953514107e-02f);
+  q = __builtin_fmaf(q, u, -1.325753778e-01f);
+  q = __builtin_fmaf(q, u, 7.977659106e-01f);
+  const float y = __builtin_fminf(__builtin_fmaxf(xc * q, -1.0f), 1.0f);
+  const float hx = 0.5f * x;
+  return __builtin_fmaf(hx, y, hx);
+}
 __device__ __forceinline__ float quick_gelu_f(float x) { return x / (1.0f + expf(-1.702f * x)); }
 
 __device__ __forceinline__ float wave_sum(float v) {

@@ -75,6 +75,16 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
 #define GEMM2_DBG(x) ((CONV || WGM * WGN == 4) && p.debug == (x))
 #endif
 
+// -DSDAMD_PP_TIMING (experiments/pp_phases.sh, never in the product build): the ping-pong kernels record s_memtime at
+// entry / first MFMA / end of the K loop / end of the epilogue per workgroup into g_pp_times (read back by
+// sdamd_debug_pp_times in gemm3.hip).
+#ifdef SDAMD_PP_TIMING
+static __device__ long long g_pp_times[4 * 8192];
+#define PP_STAMP(i) do { if (PPL && threadIdx.x == 0 && blockIdx.x < 8192 && blockIdx.y == 0) g_pp_times[4 * blockIdx.x + (i)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define PP_STAMP(i) do {} while (0)
+#endif
+
 // EPI 0: every epilogue (split-K partials, GeGLU, f32 / hi|lo, operand type), chosen at run time.
 // EPI 1: the f32 / hi|lo epilogue with an f32 residual only, the residual prefetched ahead of the K loop.
 // EPI 2: the GeGLU epilogue only (bf16).
@@ -735,6 +745,7 @@ __device__ __forceinline__ void gemm2_body(const GemmArgs& p) {
     // prologue wait: A0 + W of tile 0 landed (its A1 pieces stay in flight), visible to every wave
     wait_vmcnt<A_INS / 2>();
     __builtin_amdgcn_s_barrier();
+    PP_STAMP(1);
     if (wm == 1) __builtin_amdgcn_s_barrier();        // group 1 runs one barrier behind group 0
     // PP = 1: the B0 fragments stay in registers from p0 to p3; 2: they are re-read in p3 (16 VGPRs fewer on the 256x256
     // tile; measured 0-3 % slower, experiments/pp_bench.py).  Issuing the DMA ahead of the reads, or dropping the
@@ -842,9 +853,25 @@ __device__ __forceinline__ void gemm2_body(const GemmArgs& p) {
   // lane, consecutive lanes on consecutive addresses.  No workgroup barrier is needed after the one
   // below: a wave only reads back what it wrote itself, and LDS operations of one wave complete in
   // order.
-  __syncthreads();  // every wave is done reading the last K-tile (and no DMA is outstanding)
+  PP_STAMP(2);
   const float* __restrict__ bias = p.bias;
   const int mw = m0 + wm * WTM, nw = n0 + wn * WTN;  // this wave's sub-tile origin
+  // The bias of the wave's TN column tiles, loaded ONCE, as one batch, ahead of the barrier.  (Loaded where it is added --
+  // `if (bias && n < N) v += bias[n]` inside the row-tile x column-tile loops -- hipcc emits load, s_waitcnt vmcnt(0), use
+  // for every one of the TM x TN iterations: 16 L2 round trips in series in the GeGLU epilogue of a 256x256 tile, ~6 us of
+  // the 8.6 us that tile cost beyond its K loop; experiments/pp_phases.py.)  Columns past N read the last valid group:
+  // they are never stored.
+  const bool has_bias = bias != nullptr;
+  f32x4_t bv[TN];
+  if (has_bias) {
+    const int n_last = (p.N - 1) & ~3;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) bv[j] = *reinterpret_cast<const f32x4_t*>(bias + min(nw + j * 16 + q4 * 4, n_last));
+  } else {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) bv[j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  }
+  __syncthreads();  // every wave is done reading the last K-tile (and no DMA is outstanding)
   if (EPI == 2 || (EPI == 0 && !F32 && p.act == ACT_GEGLU)) {
     // GeGLU epilogue (diffusion.py:128-130): the weight rows were packed so that 16-column tile 2c
     // holds the value channels [16c, 16c+16) and tile 2c+1 their gates; value * gelu_erf(gate) is
@@ -867,12 +894,17 @@ __device__ __forceinline__ void gemm2_body(const GemmArgs& p) {
           for (int j = 0; j < TN; j += 2) {
             f32x4_t v = acc[j][ps * IP + ii], g = acc[j + 1][ps * IP + ii];
             const int n = nw + j * 16 + q4 * 4;
-            if (bias && n + 16 < p.N) {
-              v += *reinterpret_cast<const f32x4_t*>(bias + n);
-              g += *reinterpret_cast<const f32x4_t*>(bias + n + 16);
+            if (has_bias && n + 16 < p.N) {
+              v += bv[j];
+              g += bv[j + 1];
             }
+            if (p.debug == 29) {   // (library debug word 29: the f32-accurate erf form, for A/B runs and the accuracy test)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] *= gelu_erf_f(g[r]);
+              for (int r = 0; r < 4; ++r) v[r] *= gelu_erf_f(g[r]);
+            } else {              // the product is stored as bf16: polynomial erf, no transcendentals (common.h)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) v[r] *= gelu_erf_bf16out_f(g[r]);
+            }
             const u32x2_t o = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
             *reinterpret_cast<u32x2_t*>(slice + (ii * 16 + r16) * RS + ((j >> 1) * 16 + q4 * 4) * 2) = o;
           }
@@ -912,7 +944,7 @@ __device__ __forceinline__ void gemm2_body(const GemmArgs& p) {
         for (int j = 0; j < TN; ++j) {
           f32x4_t v = acc[j][ps * IP + ii];
           const int n = nw + j * 16 + q4 * 4;
-          if (bias && n < p.N) v += *reinterpret_cast<const f32x4_t*>(bias + n);
+          if (has_bias) v += bv[j];
           *reinterpret_cast<f32x4_t*>(slice + (ii * 16 + r16) * RS + (j * 16 + q4 * 4) * 4) = v;
         }
       }
@@ -1053,7 +1085,7 @@ __device__ __forceinline__ void gemm2_body(const GemmArgs& p) {
         for (int j = 0; j < TN; ++j) {
           f32x4_t v = acc[j][ps * IP + ii];
           const int n = nw + j * 16 + q4 * 4;
-          if (bias && n < p.N) v += *reinterpret_cast<const f32x4_t*>(bias + n);
+          if (has_bias) v += bv[j];
           if (R && m < p.M && n < p.N) {   // (bf16 residual trunks are the rare case: added before rounding)
             const u32x2_t rv = *reinterpret_cast<const u32x2_t*>(R + out_row(m) * p.ldr + n);
             v[0] += __builtin_bit_cast(float, rv[0] << 16); v[1] += __builtin_bit_cast(float, rv[0] & 0xffff0000u);

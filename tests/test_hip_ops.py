@@ -350,6 +350,41 @@ def test_gemm_fused_geglu(M, C):
     assert rel_l2(got.float().cpu(), want) <= rel_l2(unfused.float().cpu(), want) * 1.05
 
 
+def test_gemm_fused_geglu_polynomial_erf_against_the_exact_form():
+    """The fused GeGLU epilogue rounds value * gelu(gate) to bf16 at once and uses a polynomial erf (common.h
+    gelu_erf_bf16out_f: degree 17, |x| <= 4.4 clamped, no v_rcp / v_exp); library debug word 29 keeps the 1.5e-7 form.
+    Gates swept over [-9, 9] through an identity-like weight so that every regime (tails, clamp, zero crossing) is hit:
+    the two forms agree to a small fraction of a bf16 rounding step, and both sit within one rounding of float64."""
+    from sd_amd import _lib
+    L = _lib.lib()
+    M, C = 512, 320
+    # A row m carries gate g_m on every column: value weights = identity-ish picks, gate weights scale column 0
+    a = torch.zeros(M, C)
+    a[:, 0] = torch.linspace(-9.0, 9.0, M)
+    a[:, 1] = 1.0
+    w = torch.zeros(8 * C, C)
+    w[:4 * C, 1] = torch.linspace(0.5, 2.0, 4 * C)          # value_c = 0.5 .. 2
+    w[4 * C:, 0] = 1.0                                      # gate_c = g_m
+    a, w = q(a, torch.bfloat16), q(w, torch.bfloat16)
+    gate, val = a[:, 0:1].double(), w[:4 * C, 1].double()[None, :]
+    want = (val * gate * 0.5 * (1.0 + torch.erf(gate / math.sqrt(2.0)))).float()
+    args = (a.bfloat16().to(DEV), ops.geglu_pack(w.bfloat16()).to(DEV), None, None, ops.ACT_GEGLU)
+    got = ops.gemm(*args).float().cpu()
+    try:
+        L.sdamd_set_gemm_impl(29 << 8)
+        exact = ops.gemm(*args).float().cpu()
+    finally:
+        L.sdamd_set_gemm_impl(0)
+    ulp = want.abs().clamp_min(2.0 ** -126) * 2.0 ** -8      # >= half the bf16 spacing at the result (2^(e-8) for a value in [2^e, 2^(e+1)))
+    scale = 0.5 * val.float() * gate.float().abs()           # |d result / d erf|
+    assert ((exact - want).abs() <= 1.02 * ulp + scale * 3e-7 + 1e-30).all()      # A&S 7.1.26: 1.5e-7 in erf
+    # polynomial form: erf error <= 3.4e-5 -> |error| <= 0.5 |value| |gate| 3.4e-5 (+ the rounding)
+    bound = 1.02 * ulp + scale * 4e-5 + 1e-30
+    assert ((got - want).abs() <= bound).all()
+    assert rel_l2(got, want) < 3e-3 and rel_l2(got, exact) < 1e-3
+    assert torch.isfinite(got).all() and (got[gate.flatten() > 5].min() > 0)
+
+
 @pytest.mark.parametrize("M,res", [(32768, True), (32768, False), (65536 + 72, True)])
 def test_gemm_with_fused_layernorm(M, res):
     """sdamd_gemm_ln (diffusion.py:110-117: out_proj + residue, then layernorm of the sum): the f32 result equals
