@@ -214,13 +214,26 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x,
   const bool live = row < rows;
   const int nvec = C / V;
   const T* xr = x + (size_t)(live ? row : 0) * C;
+  // All of the row's vectors are requested before any is used, from clamped addresses (a load under `if (cv < nvec)` next
+  // to its use is emitted as load, s_waitcnt vmcnt(0), use: up to five HBM round trips in series per row), and gamma /
+  // beta with them: they arrive while the statistics are reduced.
   float v[LN_MAXIT][V];
+  f32x4_t gm[LN_MAXIT][V / 4], bt[LN_MAXIT][V / 4];
+#pragma unroll
+  for (int i = 0; i < LN_MAXIT; ++i) load_vec<T>(xr + (size_t)min(sub + i * LPR, nvec - 1) * V, v[i]);
+#pragma unroll
+  for (int i = 0; i < LN_MAXIT; ++i)
+#pragma unroll
+    for (int k = 0; k < V / 4; ++k) {
+      const int c0 = min(sub + i * LPR, nvec - 1) * V + 4 * k;
+      gm[i][k] = *reinterpret_cast<const f32x4_t*>(gamma + c0);
+      bt[i][k] = *reinterpret_cast<const f32x4_t*>(beta + c0);
+    }
   float sum = 0.f;
 #pragma unroll
   for (int i = 0; i < LN_MAXIT; ++i) {
     int cv = sub + i * LPR;
     if (cv < nvec) {
-      load_vec<T>(xr + (size_t)cv * V, v[i]);
 #pragma unroll
       for (int j = 0; j < V; ++j) sum += v[i][j];
     }
@@ -249,10 +262,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x,
       float o[V];
 #pragma unroll
       for (int k = 0; k < V / 4; ++k) {
-        const f32x4_t gm = *reinterpret_cast<const f32x4_t*>(gamma + cv * V + 4 * k);
-        const f32x4_t bt = *reinterpret_cast<const f32x4_t*>(beta + cv * V + 4 * k);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) o[4 * k + j] = (v[i][4 * k + j] - mean) * rstd * gm[j] + bt[j];
+        for (int j = 0; j < 4; ++j) o[4 * k + j] = (v[i][4 * k + j] - mean) * rstd * gm[i][k][j] + bt[i][k][j];
       }
       store_n<TO, V>(yr + (size_t)cv * V, o);
     }
