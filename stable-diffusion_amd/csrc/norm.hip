@@ -315,28 +315,37 @@ __global__ __launch_bounds__(NT) void gn_group_kernel(const T* __restrict__ x, c
     for (int w = 0; w < NT / 64; ++w) tot += s_red[w];
     return tot;
   };
+  // All of the thread's items are requested before any is used (a load under `if (t + NT * k < items)` next to its use is
+  // emitted as load, s_waitcnt vmcnt(0), use: up to GNG_MAXP HBM round trips in series); items past the end re-read the
+  // thread's first one (or item 0) and are not accumulated.
   float v[GNG_MAXP][2];
   float sum = 0.f;
   {
     int px = t / ppp, pc = t - px * ppp;
+    const int px0 = t < items ? px : 0, pc0 = t < items ? pc : 0;
+    typedef typename std::conditional<sizeof(T) == 4, f32x2_t, unsigned>::type raw_t;
+    raw_t raw[GNG_MAXP];
+#pragma unroll
+    for (int k = 0; k < GNG_MAXP; ++k) {
+      const bool ok = t + NT * k < items;
+      const int pxk = ok ? px : px0, c = c_base + 2 * (ok ? pc : pc0);
+      const T* src = !x2 ? x + ((size_t)n * HW + pxk) * C + c
+                         : c < C1 ? x + ((size_t)n * HW + pxk) * C1 + c : x2 + ((size_t)n * HW + pxk) * (C - C1) + (c - C1);
+      raw[k] = *reinterpret_cast<const raw_t*>(src);
+      px += dp; pc += dc;
+      if (pc >= ppp) { pc -= ppp; ++px; }
+    }
 #pragma unroll
     for (int k = 0; k < GNG_MAXP; ++k) {
       v[k][0] = v[k][1] = 0.f;
       if (t + NT * k < items) {
-        const int c = c_base + 2 * pc;
-        const T* src = !x2 ? x + ((size_t)n * HW + px) * C + c
-                           : c < C1 ? x + ((size_t)n * HW + px) * C1 + c : x2 + ((size_t)n * HW + px) * (C - C1) + (c - C1);
         if constexpr (sizeof(T) == 4) {
-          const f32x2_t u = *reinterpret_cast<const f32x2_t*>(src);
-          v[k][0] = u[0]; v[k][1] = u[1];
+          v[k][0] = raw[k][0]; v[k][1] = raw[k][1];
         } else {
-          const unsigned u = *reinterpret_cast<const unsigned*>(src);
-          v[k][0] = __builtin_bit_cast(float, u << 16); v[k][1] = __builtin_bit_cast(float, u & 0xffff0000u);
+          v[k][0] = __builtin_bit_cast(float, raw[k] << 16); v[k][1] = __builtin_bit_cast(float, raw[k] & 0xffff0000u);
         }
         sum += v[k][0] + v[k][1];
       }
-      px += dp; pc += dc;
-      if (pc >= ppp) { pc -= ppp; ++px; }
     }
   }
   const float cnt = (float)HW * (float)cpg;
@@ -348,11 +357,24 @@ __global__ __launch_bounds__(NT) void gn_group_kernel(const T* __restrict__ x, c
   const float rstd = 1.0f / sqrtf(block_sum(sq) / cnt + eps);
   {
     int px = t / ppp, pc = t - px * ppp;
+    const int pc0 = t < items ? pc : 0;
+    f32x2_t gav[GNG_MAXP], bev[GNG_MAXP];               // gamma / beta of every item, one batch (as above)
+    {
+      int qc = pc;
+#pragma unroll
+      for (int k = 0; k < GNG_MAXP; ++k) {
+        const int c = c_base + 2 * (t + NT * k < items ? qc : pc0);
+        gav[k] = *reinterpret_cast<const f32x2_t*>(gamma + c);
+        bev[k] = *reinterpret_cast<const f32x2_t*>(beta + c);
+        qc += dc;
+        if (qc >= ppp) qc -= ppp;
+      }
+    }
 #pragma unroll
     for (int k = 0; k < GNG_MAXP; ++k) {
       if (t + NT * k < items) {
         const int c = c_base + 2 * pc;
-        const f32x2_t ga = *reinterpret_cast<const f32x2_t*>(gamma + c), be = *reinterpret_cast<const f32x2_t*>(beta + c);
+        const f32x2_t ga = gav[k], be = bev[k];
         float r[2];
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
