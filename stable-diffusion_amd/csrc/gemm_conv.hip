@@ -205,6 +205,24 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
   const bool of32 = p.out_f32 || sizeof(T) == 4;
   const T* __restrict__ R = (p.R && !of32) ? (const T*)p.R + (size_t)batch * p.sR : nullptr;
   const float* __restrict__ Rf = (p.R && of32) ? (const float*)p.R + (size_t)batch * p.sR : nullptr;
+  // Bias and f32 residual of every (row tile, column tile) of the lane are requested first, as one batch, from clamped
+  // addresses (loaded under `if (m < M && n < N)` next to their use they cost one memory round trip each, in series:
+  // hipcc emits load, s_waitcnt vmcnt(0), use per iteration); out-of-range tiles are not stored.
+  const int m_last = p.M - 1, n_last = (p.N - 1) & ~3;
+  f32x4_t bv[TN], rvv[TM][TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    bv[j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    if (bias) bv[j] = *reinterpret_cast<const f32x4_t*>(bias + min(n0 + wn * (BN / 2) + j * 16 + q4 * 4, n_last));
+  }
+  if (Rf) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        rvv[i][j] = *reinterpret_cast<const f32x4_t*>(Rf + (size_t)min(m0 + wm * (BM / 2) + i * 16 + r16, m_last) * p.ldr +
+                                                      min(n0 + wn * (BN / 2) + j * 16 + q4 * 4, n_last));
+  }
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     const int m = m0 + wm * (BM / 2) + i * 16 + r16;
@@ -215,14 +233,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
       if (n >= p.N) continue;
       float v[4] = {acc[j][i][0], acc[j][i][1], acc[j][i][2], acc[j][i][3]};
       if (bias) {
-        f32x4_t b = *reinterpret_cast<const f32x4_t*>(bias + n);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] += b[r];
+        for (int r = 0; r < 4; ++r) v[r] += bv[j][r];
       }
       if (Rf) {
-        const f32x4_t rv = *reinterpret_cast<const f32x4_t*>(Rf + (size_t)m * p.ldr + n);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] += rv[r];
+        for (int r = 0; r < 4; ++r) v[r] += rvv[i][j][r];
       } else if (R) {
         const T* rp = R + (size_t)m * p.ldr + n;
 #pragma unroll
