@@ -23,11 +23,35 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
       const int y = rem / p.Wo, x = rem - y * p.Wo;
       m = ((size_t)n_img * 2 * p.Ho + 2 * y + (p.phase_base >> 1)) * (2 * p.Wo) + 2 * x + (p.phase_base & 1);
     }
-    for (int s = 1; s < p.splits; ++s) v += *reinterpret_cast<const f32x4_t*>(p.ws + s * slab + m_in * p.N + n);
-    if (p.bias) v += *reinterpret_cast<const f32x4_t*>(p.bias + n);
+    // The other splits' partial sums, the bias and an f32 residual are requested as ONE batch and added in the same order
+    // as before (split 1, 2, ..., bias, residual): in a loop of unknown length, or under `if (p.bias)` next to its use,
+    // every load is waited for before the next one is issued -- splits + 2 memory round trips in series per thread.
+    const float* wsp = p.ws + m_in * p.N + n;
+    const bool r32 = p.R && p.out_f32;
+    f32x4_t bb = {0.f, 0.f, 0.f, 0.f}, rr = {0.f, 0.f, 0.f, 0.f};
+    auto batch = [&](auto SC) {
+      constexpr int S = decltype(SC)::value;
+      f32x4_t part[S > 1 ? S - 1 : 1];
+#pragma unroll
+      for (int s = 1; s < S; ++s) part[s - 1] = *reinterpret_cast<const f32x4_t*>(wsp + s * slab);
+      if (p.bias) bb = *reinterpret_cast<const f32x4_t*>(p.bias + n);
+      if (r32) rr = *reinterpret_cast<const f32x4_t*>((const float*)p.R + m * p.ldr + n);
+#pragma unroll
+      for (int s = 1; s < S; ++s) v += part[s - 1];
+    };
+    switch (p.splits) {   // (uniform)
+      case 2: batch(std::integral_constant<int, 2>{}); break;
+      case 3: batch(std::integral_constant<int, 3>{}); break;
+      case 4: batch(std::integral_constant<int, 4>{}); break;
+      case 8: batch(std::integral_constant<int, 8>{}); break;
+      default:
+        for (int s = 1; s < p.splits; ++s) v += *reinterpret_cast<const f32x4_t*>(wsp + s * slab);
+        batch(std::integral_constant<int, 1>{});
+    }
+    if (p.bias) v += bb;
     if (p.R) {
       if (p.out_f32) {
-        v += *reinterpret_cast<const f32x4_t*>((const float*)p.R + m * p.ldr + n);
+        v += rr;
       } else {
         const u32x2_t rv = *reinterpret_cast<const u32x2_t*>((const bf16_t*)p.R + m * p.ldr + n);
         v[0] += __builtin_bit_cast(float, rv[0] << 16); v[1] += __builtin_bit_cast(float, rv[0] & 0xffff0000u);
