@@ -481,11 +481,21 @@ __global__ __launch_bounds__(256) void gn_finalize_pre_kernel(const float* __res
   const int g = blockIdx.x, n = blockIdx.y, t = threadIdx.x;
   const int C = C1 + C2, cpg = C / 32, nrb = HW / 64;
   double ss = 0.0, qq = 0.0;
-  for (int e = t; e < nrb * cpg; e += 256) {
-    const int rb = e / cpg, c = g * cpg + (e - rb * cpg);
-    const float* src = c < C1 ? s1 + ((size_t)(n * nrb + rb) * C1 + c) * 2 : s2 + ((size_t)(n * nrb + rb) * C2 + (c - C1)) * 2;
-    const f32x2_t v = *reinterpret_cast<const f32x2_t*>(src);
-    ss += (double)v[0]; qq += (double)v[1];
+  // four entries per thread requested at a time (clamped addresses; one per iteration is load, wait, add in series), added
+  // in the same order as a plain loop
+  const int tot = nrb * cpg;
+  for (int e0 = t; e0 < tot; e0 += 4 * 256) {
+    f32x2_t v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e = min(e0 + 256 * u, tot - 1);
+      const int rb = e / cpg, c = g * cpg + (e - rb * cpg);
+      const float* src = c < C1 ? s1 + ((size_t)(n * nrb + rb) * C1 + c) * 2 : s2 + ((size_t)(n * nrb + rb) * C2 + (c - C1)) * 2;
+      v[u] = *reinterpret_cast<const f32x2_t*>(src);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (e0 + 256 * u < tot) { ss += (double)v[u][0]; qq += (double)v[u][1]; }
   }
   ss = wave_sum_d(ss); qq = wave_sum_d(qq);
   if ((t & 63) == 0) { red[0][t >> 6] = ss; red[1][t >> 6] = qq; }
