@@ -1,44 +1,62 @@
-"""Where a 256x256 ping-pong (GeGLU) tile's time goes: per-workgroup s_memtime stamps at kernel entry / first MFMA /
-end of the K loop / end of the epilogue, from the -DSDAMD_PP_TIMING build (experiments/build_pp_timing.sh).
-usage: SDAMD_LIB=experiments/micro/libsdamd_pptiming.so python experiments/pp_phases.py"""
-import os, sys, ctypes
+"""Where a GEMM / conv workgroup's time goes: per-workgroup s_memtime stamps at kernel entry / (ping-pong loop: first MFMA) /
+end of the K loop / end of the epilogue, from the -DSDAMD_PP_TIMING build (experiments/build_pp_timing.sh), which writes them
+into the split-K workspace of un-split launches.
+usage: SDAMD_LIB=$PWD/experiments/micro/libsdamd_pptiming.so python experiments/pp_phases.py"""
+import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import sd_amd
-from sd_amd import ops, _lib
+from sd_amd import ops
 torch.set_grad_enabled(False)
-L = _lib.lib()
-L.sdamd_debug_pp_times.restype = ctypes.c_int
-L.sdamd_debug_pp_times.argtypes = [ctypes.c_void_p, ctypes.c_int]
-dev = "cuda"
-for (M, N, K) in ((65536, 2560, 320), (16384, 5120, 640), (4096, 10240, 1280)):
-    a = torch.randn(M, K, device=dev).bfloat16(); w = (torch.randn(N, K, device=dev) * K ** -0.5).bfloat16(); b = torch.randn(N, device=dev)
-    f = lambda: ops.gemm(a, w, b, None, ops.ACT_GEGLU)
-    for _ in range(3): f()
+dev = torch.device("cuda")
+bf = torch.bfloat16
+def rn(*shape, s=1.0): return (torch.randn(*shape, device=dev) * s)
+cases = []
+def gemm_case(name, M, N, K, res=False, f32=False, geglu=False, ln=False):
+    a = rn(M, K).to(bf); w = rn(N, K, s=K ** -0.5).to(bf); b = rn(N); r = rn(M, N) if res else None
+    if ln:
+        g, be = rn(N), rn(N)
+        cases.append((name, lambda: ops.gemm_ln(a, w, b, r, g, be, 1e-5)))
+    else:
+        cases.append((name, lambda: ops.gemm(a, w, b, r, ops.ACT_GEGLU if geglu else ops.ACT_NONE, out_f32=f32 or res)))
+def conv_case(name, B, HW, Cin, Cout, res=False, f32=False):
+    x = rn(B, HW, HW, Cin).to(bf); w = rn(Cout, 9 * Cin, s=(9 * Cin) ** -0.5).to(bf); b = rn(Cout)
+    r = rn(B, HW, HW, Cout) if res else None
+    cases.append((name, lambda: ops.conv3x3(x, w, b, r, out_f32=f32 or res)))
+gemm_case("GeGLU 256x256 M65536 N2560 K320", 65536, 2560, 320, geglu=True)
+gemm_case("GeGLU 256x256 M16384 N5120 K640", 16384, 5120, 640, geglu=True)
+gemm_case("QKV 128x320 M65536 N960 K320 (bf16 out)", 65536, 960, 320)
+gemm_case("out-proj + LN 128x320 M65536 N320 K320 +res", 65536, 320, 320, res=True, ln=True)
+gemm_case("128x160 M16384 N640 K640 +res f32", 16384, 640, 640, res=True)
+gemm_case("128x160 M16384 N1920 K640 (bf16 out)", 16384, 1920, 640)
+gemm_case("128x160 M4096 N1280 K1280 +res f32", 4096, 1280, 1280, res=True)
+conv_case("conv halo-128 B16 64x64 320->320 +res f32", 16, 64, 320, 320, res=True)
+conv_case("conv halo-128 B16 64x64 640->320", 16, 64, 640, 320)
+conv_case("conv halo-128 B16 32x32 640->640 +res f32", 16, 32, 640, 640, res=True)
+conv_case("conv big-wave B16 32x32 1280->640", 16, 32, 1280, 640)
+ws = ops._gemm_workspace(dev)
+wsi = ws.view(torch.int64) if ws.dtype != torch.int64 else ws
+for name, f in cases:
+    for _ in range(2): f()
     torch.cuda.synchronize()
+    wsi[:4 * 8192].zero_()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record(); f(); e.record(); torch.cuda.synchronize()
-    ntile = (M // 256) * (N // 256)
-    buf = np.zeros(4 * 8192, dtype=np.int64)
-    rc = L.sdamd_debug_pp_times(buf.ctypes.data, buf.size); assert rc == 0
-    t = buf.reshape(-1, 4)[:ntile].astype(np.float64)
-    xcd = np.arange(ntile) % 8                                 # the counters of the 8 XCDs are not synchronised
-    for x in range(8): t[xcd == x] -= t[xcd == x, 0].min()
     us = s.elapsed_time(e) * 1e3
-    clk = np.mean([t[xcd == x, 3].max() for x in range(8)]) / us    # ticks per us (a launch spans the event time on every XCD)
-    d = np.stack([t[:, 1] - t[:, 0], t[:, 2] - t[:, 1], t[:, 3] - t[:, 2]], 1) / clk
-    order = np.argsort(t[:, 0]); start = t[order, 0] / clk
-    print(f"M{M} N{N} K{K}: {ntile} tiles, launch {us:.1f} us, {clk:.0f} ticks/us")
-    print(f"   per workgroup (us, mean / p10 / p90): entry->first MFMA {d[:,0].mean():.2f} / {np.percentile(d[:,0],10):.2f} / {np.percentile(d[:,0],90):.2f}"
-          f"   K loop {d[:,1].mean():.2f} / {np.percentile(d[:,1],10):.2f} / {np.percentile(d[:,1],90):.2f}"
-          f"   epilogue {d[:,2].mean():.2f} / {np.percentile(d[:,2],10):.2f} / {np.percentile(d[:,2],90):.2f}   whole {((t[:,3]-t[:,0])/clk).mean():.2f}")
-    r = [start[i:i + 256].mean() for i in range(0, ntile, 256)]
-    print("   mean entry time of successive groups of 256 workgroups (us):", " ".join(f"{x:.1f}" for x in r[:12]))
-    # per XCD: the 32 CUs run one workgroup each; gap between the k-th end and the (k+32)-th entry
-    gaps = []
-    for x in range(8):
-        st = np.sort(t[xcd == x, 0]) / clk; en = np.sort(t[xcd == x, 3]) / clk
-        if len(st) > 32: gaps.append(st[32:] - en[:len(st) - 32])
-    if gaps:
-        gap = np.concatenate(gaps)
-        print(f"   per XCD: (k+32)-th entry minus k-th end (us): mean {gap.mean():.2f}  p10 {np.percentile(gap,10):.2f}  p90 {np.percentile(gap,90):.2f}")
+    t = wsi[:4 * 8192].cpu().numpy().reshape(-1, 4).astype(np.float64)
+    live = t[:, 0] > 0
+    n = int(live.sum())
+    if n == 0:
+        print(f"{name}: launch {us:.1f} us -- no stamps (split launch?)"); continue
+    t = t[live]
+    has1 = (t[:, 1] > 0).all()
+    whole = t[:, 3] - t[:, 0]
+    pre = (t[:, 1] - t[:, 0]) if has1 else np.zeros(n)
+    loop = t[:, 2] - (t[:, 1] if has1 else t[:, 0])
+    epi = t[:, 3] - t[:, 2]
+    # the XCDs' counters are not synchronised: only differences inside a workgroup are meaningful.  Scale: ticks of a
+    # workgroup's lifetime x (workgroups / resident slots) ~ launch time; report shares and the implied microseconds
+    sh = lambda x: 100.0 * x.mean() / whole.mean()
+    print(f"{name}: {n} workgroups, launch {us:.1f} us; a workgroup's life: "
+          + (f"before first MFMA {sh(pre):.0f} %, K loop {sh(loop):.0f} %" if has1 else f"prologue + K loop {sh(loop):.0f} %")
+          + f", epilogue {sh(epi):.0f} %   (ticks: whole {whole.mean():.0f}, epilogue {epi.mean():.0f}, p90 {np.percentile(epi, 90):.0f})", flush=True)

@@ -75,12 +75,16 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
 #define GEMM2_DBG(x) ((CONV || WGM * WGN == 4) && p.debug == (x))
 #endif
 
-// -DSDAMD_PP_TIMING (experiments/pp_phases.sh, never in the product build): the ping-pong kernels record s_memtime at
-// entry / first MFMA / end of the K loop / end of the epilogue per workgroup into g_pp_times (read back by
-// sdamd_debug_pp_times in gemm3.hip).
+// -DSDAMD_PP_TIMING (experiments/build_pp_timing.sh, never in the product build): every un-split launch of gemm2_body
+// records s_memtime per workgroup -- at entry / first MFMA (ping-pong loop only) / end of the K loop / end of the epilogue
+// -- into the split-K workspace it was handed and does not use (GemmArgs::ws; experiments/pp_phases.py reads it back).
 #ifdef SDAMD_PP_TIMING
-static __device__ long long g_pp_times[4 * 8192];
-#define PP_STAMP(i) do { if (PPL && threadIdx.x == 0 && blockIdx.x < 8192 && blockIdx.y == 0) g_pp_times[4 * blockIdx.x + (i)] = __builtin_readcyclecounter(); } while (0)
+#define PP_STAMP(i) do { if (p.splits == 1 && p.ws && threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x < 8192) \
+    reinterpret_cast<long long*>(p.ws)[4 * blockIdx.x + (i)] = __builtin_readcyclecounter(); } while (0)
+struct PPStampEnd {
+  const GemmArgs& p;
+  __device__ ~PPStampEnd() { PP_STAMP(3); }
+};
 #else
 #define PP_STAMP(i) do {} while (0)
 #endif
@@ -100,6 +104,10 @@ static __device__ long long g_pp_times[4 * 8192];
 //     11 = the big-wave loop on 8 x 8 images (a 256-row tile = four whole images; split-K launches only).
 template <typename T, int BM, int BN, int WGM, int WGN, int STAGES, bool CONV, int EPI, int PP>
 __device__ __forceinline__ void gemm2_body(const GemmArgs& p) {
+#ifdef SDAMD_PP_TIMING
+  PP_STAMP(0);
+  PPStampEnd pp_stamp_end{p};
+#endif
   constexpr bool PPL = PP == 1 || PP == 2;
   constexpr int HALO_W = (PP == 3 || PP == 6) ? 64 : (PP == 4 || PP == 7 || PP == 9) ? 32 : (PP == 5 || PP == 8 || PP == 10) ? 16 : PP == 11 ? 8 : 0;
   constexpr bool HUP = PP == 9 || PP == 10;            // big-wave halo loop on the phase form of upsample + conv3x3: 4 taps (2 x 2) per phase

@@ -6,19 +6,8 @@
 
 template <typename T, int BM, int BN, int WGM, int WGN, int STAGES, bool CONV, int EPI, int PPV>
 __global__ __launch_bounds__(WGM* WGN * 64) void gemm2pp_kernel(const GemmArgs p) {
-#ifdef SDAMD_PP_TIMING
-  if (threadIdx.x == 0 && blockIdx.x < 8192 && blockIdx.y == 0) g_pp_times[4 * blockIdx.x] = __builtin_readcyclecounter();
-#endif
   gemm2_body<T, BM, BN, WGM, WGN, STAGES, CONV, EPI, PPV>(p);
-#ifdef SDAMD_PP_TIMING
-  if (threadIdx.x == 0 && blockIdx.x < 8192 && blockIdx.y == 0) g_pp_times[4 * blockIdx.x + 3] = __builtin_readcyclecounter();
-#endif
 }
-#ifdef SDAMD_PP_TIMING
-extern "C" int sdamd_debug_pp_times(long long* out, int n) {   // experiment builds only (experiments/build_pp_timing.sh)
-  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pp_times), (size_t)(n < 4 * 8192 ? n : 4 * 8192) * sizeof(long long));
-}
-#endif
 
 template <int BM, int BN, bool CONV, int EPI, int PPV>
 static int launch_pp_epi(GemmArgs& a, int batch, hipStream_t st) {
