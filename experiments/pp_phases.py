@@ -39,11 +39,11 @@ wsi = ws.view(torch.int64) if ws.dtype != torch.int64 else ws
 for name, f in cases:
     for _ in range(2): f()
     torch.cuda.synchronize()
-    wsi[:4 * 8192].zero_()
+    wsi[:8 * 4096].zero_()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record(); f(); e.record(); torch.cuda.synchronize()
     us = s.elapsed_time(e) * 1e3
-    t = wsi[:4 * 8192].cpu().numpy().reshape(-1, 4).astype(np.float64)
+    t = wsi[:8 * 4096].cpu().numpy().reshape(-1, 8).astype(np.float64)
     live = t[:, 0] > 0
     n = int(live.sum())
     if n == 0:
@@ -60,3 +60,6 @@ for name, f in cases:
     print(f"{name}: {n} workgroups, launch {us:.1f} us; a workgroup's life: "
           + (f"before first MFMA {sh(pre):.0f} %, K loop {sh(loop):.0f} %" if has1 else f"prologue + K loop {sh(loop):.0f} %")
           + f", epilogue {sh(epi):.0f} %   (ticks: whole {whole.mean():.0f}, epilogue {epi.mean():.0f}, p90 {np.percentile(epi, 90):.0f})", flush=True)
+    if (t[:, 4] > 0).all() and (t[:, 5] > 0).all() and (t[:, 6] > 0).all():
+        print(f"      inside the epilogue (ticks, mean): bias loads + barrier {(t[:,4]-t[:,2]).mean():.0f}, first pass into LDS {(t[:,5]-t[:,4]).mean():.0f}, "
+              f"first pass stored {(t[:,6]-t[:,5]).mean():.0f}, the rest {(t[:,3]-t[:,6]).mean():.0f}", flush=True)

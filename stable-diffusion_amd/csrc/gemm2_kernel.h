@@ -77,10 +77,11 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
 
 // -DSDAMD_PP_TIMING (experiments/build_pp_timing.sh, never in the product build): every un-split launch of gemm2_body
 // records s_memtime per workgroup -- at entry / first MFMA (ping-pong loop only) / end of the K loop / end of the epilogue
-// -- into the split-K workspace it was handed and does not use (GemmArgs::ws; experiments/pp_phases.py reads it back).
+// (slots 0-3; 4-6: after the epilogue's barrier / first pass staged in LDS / first pass stored) -- into the split-K
+// workspace it was handed and does not use (GemmArgs::ws; experiments/pp_phases.py reads it back).
 #ifdef SDAMD_PP_TIMING
-#define PP_STAMP(i) do { if (p.splits == 1 && p.ws && threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x < 8192) \
-    reinterpret_cast<long long*>(p.ws)[4 * blockIdx.x + (i)] = __builtin_readcyclecounter(); } while (0)
+#define PP_STAMP(i) do { if (p.splits == 1 && p.ws && threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x < 4096) \
+    reinterpret_cast<long long*>(p.ws)[8 * blockIdx.x + (i)] = __builtin_readcyclecounter(); } while (0)
 struct PPStampEnd {
   const GemmArgs& p;
   __device__ ~PPStampEnd() { PP_STAMP(3); }
@@ -880,6 +881,7 @@ __device__ __forceinline__ void gemm2_body(const GemmArgs& p) {
     for (int j = 0; j < TN; ++j) bv[j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
   }
   __syncthreads();  // every wave is done reading the last K-tile (and no DMA is outstanding)
+  PP_STAMP(4);   // (slots 4..6: after the barrier / first pass staged in LDS / first pass stored)
   if (EPI == 2 || (EPI == 0 && !F32 && p.act == ACT_GEGLU)) {
     // GeGLU epilogue (diffusion.py:128-130): the weight rows were packed so that 16-column tile 2c
     // holds the value channels [16c, 16c+16) and tile 2c+1 their gates; value * gelu_erf(gate) is
@@ -918,6 +920,7 @@ __device__ __forceinline__ void gemm2_body(const GemmArgs& p) {
           }
         }
         __builtin_amdgcn_wave_barrier();
+        if (ps == 0) PP_STAMP(5);
         for (int idx = lane; idx < IP * 16 * CPR; idx += 64) {
           const int row = idx / CPR, ch = idx - row * CPR;
           const int m = mw + ps * IP * 16 + row, n = nwo + ch * 8;
@@ -925,6 +928,7 @@ __device__ __forceinline__ void gemm2_body(const GemmArgs& p) {
           if (m < p.M && n < (p.N >> 1)) *reinterpret_cast<u32x4_t*>(C + out_row(m) * p.ldc + n) = v;
         }
         __builtin_amdgcn_wave_barrier();
+        if (ps == 0) PP_STAMP(6);
       }
     }
   } else if (EPI != 2 && (RPRE || F32 || p.out_f32)) {
@@ -957,6 +961,7 @@ __device__ __forceinline__ void gemm2_body(const GemmArgs& p) {
         }
       }
       __builtin_amdgcn_wave_barrier();
+      if (ps == 0) PP_STAMP(5);
       auto finish = [&](int idx, f32x4_t r, bool have_r) {   // row-segment chunk idx of this pass: residual, activation, store
         const int row = idx / CPR, ch = idx - row * CPR;
         const int m = mw + ps * IP * 16 + row, n = nw + ch * 4;
@@ -991,6 +996,7 @@ __device__ __forceinline__ void gemm2_body(const GemmArgs& p) {
         for (int idx = lane; idx < IP * 16 * CPR; idx += 64) finish(idx, (f32x4_t){0.f, 0.f, 0.f, 0.f}, false);
       }
       __builtin_amdgcn_wave_barrier();
+      if (ps == 0) PP_STAMP(6);
       if (do_stats) {
         const int row0 = mw + ps * IP * 16;
         const int nrow = min(IP * 16, p.M - row0);          // rows of this pass inside the matrix
@@ -1111,6 +1117,7 @@ __device__ __forceinline__ void gemm2_body(const GemmArgs& p) {
         }
       }
       __builtin_amdgcn_wave_barrier();
+      if (ps == 0) PP_STAMP(5);
       for (int idx = lane; idx < IP * 16 * CPR; idx += 64) {
         const int row = idx / CPR, ch = idx - row * CPR;
         const int m = mw + ps * IP * 16 + row, n = nw + ch * 8;
@@ -1144,6 +1151,7 @@ __device__ __forceinline__ void gemm2_body(const GemmArgs& p) {
         }
       }
       __builtin_amdgcn_wave_barrier();
+      if (ps == 0) PP_STAMP(6);
     }
   }
 }
