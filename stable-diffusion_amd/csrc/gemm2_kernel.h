@@ -1082,6 +1082,7 @@ __device__ __forceinline__ void gemm2_body(const GemmArgs& p) {
     static_assert(WTM % 64 != 0 || 64 % (IP * 16) == 0, "column statistics: an epilogue pass must not span two 64-row blocks");
     char* const slice = smem + wave * (IP * 16 * RS);
     const bf16_t* __restrict__ R = p.R ? (const bf16_t*)p.R + (size_t)batch * p.sR : nullptr;
+    const bool plain = !R && p.act == ACT_NONE;
     bf16_t* __restrict__ C = (bf16_t*)p.C + (size_t)batch * p.sC;
     // column statistics (GemmArgs::colstats) of the ROUNDED values, as a GroupNorm reading the bf16 tensor would see them:
     // a lane sums one pair of adjacent columns over the pass's rows
@@ -1100,17 +1101,21 @@ __device__ __forceinline__ void gemm2_body(const GemmArgs& p) {
           f32x4_t v = acc[j][ps * IP + ii];
           const int n = nw + j * 16 + q4 * 4;
           if (has_bias) v += bv[j];
-          if (R && m < p.M && n < p.N) {   // (bf16 residual trunks are the rare case: added before rounding)
-            const u32x2_t rv = *reinterpret_cast<const u32x2_t*>(R + out_row(m) * p.ldr + n);
-            v[0] += __builtin_bit_cast(float, rv[0] << 16); v[1] += __builtin_bit_cast(float, rv[0] & 0xffff0000u);
-            v[2] += __builtin_bit_cast(float, rv[1] << 16); v[3] += __builtin_bit_cast(float, rv[1] & 0xffff0000u);
-          }
-          if (p.act == ACT_QUICK_GELU) {
+          // (`plain` -- no bf16 residual, no activation: nearly every launch -- is tested once per tile instead of three
+          //  launch-uniform tests per 16x16 sub-tile, each of which ended a basic block)
+          if (!plain) {
+            if (R && m < p.M && n < p.N) {   // (bf16 residual trunks are the rare case: added before rounding)
+              const u32x2_t rv = *reinterpret_cast<const u32x2_t*>(R + out_row(m) * p.ldr + n);
+              v[0] += __builtin_bit_cast(float, rv[0] << 16); v[1] += __builtin_bit_cast(float, rv[0] & 0xffff0000u);
+              v[2] += __builtin_bit_cast(float, rv[1] << 16); v[3] += __builtin_bit_cast(float, rv[1] & 0xffff0000u);
+            }
+            if (p.act == ACT_QUICK_GELU) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = quick_gelu_f(v[r]);
-          } else if (p.act == ACT_SILU) {
+              for (int r = 0; r < 4; ++r) v[r] = quick_gelu_f(v[r]);
+            } else if (p.act == ACT_SILU) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = silu_f(v[r]);
+              for (int r = 0; r < 4; ++r) v[r] = silu_f(v[r]);
+            }
           }
           const u32x2_t o = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
           *reinterpret_cast<u32x2_t*>(slice + (ii * 16 + r16) * RS + (j * 16 + q4 * 4) * 2) = o;
