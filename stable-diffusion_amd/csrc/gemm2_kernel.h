@@ -944,6 +944,7 @@ __device__ __forceinline__ void gemm2_body(const GemmArgs& p) {
     // column statistics of the stored values for a following GroupNorm (GemmArgs::colstats): the finished chunks go
     // back into the wave's LDS slice and every lane then sums one (or two) columns over the pass's rows
     const bool do_stats = p.colstats != nullptr;
+    const bool plain32 = p.act == ACT_NONE && p.out_f32 != 2 && !do_stats && !LNF;
     constexpr int NCR = (WTN + 63) / 64;
     float cs[NCR], cq[NCR];
 #pragma unroll
@@ -962,21 +963,24 @@ __device__ __forceinline__ void gemm2_body(const GemmArgs& p) {
       }
       __builtin_amdgcn_wave_barrier();
       if (ps == 0) PP_STAMP(5);
-      auto finish = [&](int idx, f32x4_t r, bool have_r) {   // row-segment chunk idx of this pass: residual, activation, store
+      // (PLAIN: no activation, no hi|lo output, nothing kept for statistics / LayerNorm -- tested once per pass instead of
+      //  four launch-uniform tests per chunk, each of which ended a basic block)
+      auto finish = [&](auto PLAIN, int idx, f32x4_t r, bool have_r) {   // row-segment chunk idx of this pass: residual, activation, store
+        constexpr bool plain = decltype(PLAIN)::value;
         const int row = idx / CPR, ch = idx - row * CPR;
         const int m = mw + ps * IP * 16 + row, n = nw + ch * 4;
         f32x4_t v = *reinterpret_cast<const f32x4_t*>(slice + row * RS + ch * 16);
         if (m < p.M && n < p.N) {
           if (have_r) v += r;
           else if (Rf) v += *reinterpret_cast<const f32x4_t*>(Rf + out_row(m) * p.ldr + n);
-          if (p.act == ACT_QUICK_GELU) {
+          if (!plain && p.act == ACT_QUICK_GELU) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = quick_gelu_f(v[r]);
-          } else if (p.act == ACT_SILU) {
+          } else if (!plain && p.act == ACT_SILU) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = silu_f(v[r]);
           }
-          if (p.out_f32 == 2) {   // hi|lo: [bf16(v) | bf16(v - bf16(v))] at columns n and N + n of a bf16 [M][2N] matrix
+          if (!plain && p.out_f32 == 2) {   // hi|lo: [bf16(v) | bf16(v - bf16(v))] at columns n and N + n of a bf16 [M][2N] matrix
             bf16_t* Ch = (bf16_t*)p.C + (size_t)batch * p.sC + out_row(m) * p.ldc + n;
             float hi[4], lo[4];
 #pragma unroll
@@ -986,14 +990,19 @@ __device__ __forceinline__ void gemm2_body(const GemmArgs& p) {
           } else {
             *reinterpret_cast<f32x4_t*>(C + out_row(m) * p.ldc + n) = v;
           }
-          if (do_stats || LNF) *reinterpret_cast<f32x4_t*>(slice + row * RS + ch * 16) = v;
+          if (!plain && (do_stats || LNF)) *reinterpret_cast<f32x4_t*>(slice + row * RS + ch * 16) = v;
         }
       };
       if constexpr (RPRE) {
+        if (plain32) {
 #pragma unroll
-        for (int it = 0; it < E_IT; ++it) finish(lane + it * 64, rpre[ps * E_IT + it], true);
+          for (int it = 0; it < E_IT; ++it) finish(std::true_type{}, lane + it * 64, rpre[ps * E_IT + it], true);
+        } else {
+#pragma unroll
+          for (int it = 0; it < E_IT; ++it) finish(std::false_type{}, lane + it * 64, rpre[ps * E_IT + it], true);
+        }
       } else {
-        for (int idx = lane; idx < IP * 16 * CPR; idx += 64) finish(idx, (f32x4_t){0.f, 0.f, 0.f, 0.f}, false);
+        for (int idx = lane; idx < IP * 16 * CPR; idx += 64) finish(std::false_type{}, idx, (f32x4_t){0.f, 0.f, 0.f, 0.f}, false);
       }
       __builtin_amdgcn_wave_barrier();
       if (ps == 0) PP_STAMP(6);
