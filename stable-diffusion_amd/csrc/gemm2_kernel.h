@@ -944,7 +944,8 @@ __device__ __forceinline__ void gemm2_body(const GemmArgs& p) {
     // column statistics of the stored values for a following GroupNorm (GemmArgs::colstats): the finished chunks go
     // back into the wave's LDS slice and every lane then sums one (or two) columns over the pass's rows
     const bool do_stats = p.colstats != nullptr;
-    const bool plain32 = p.act == ACT_NONE && p.out_f32 != 2 && !do_stats && !LNF;
+    // (1 plain, 2 hi|lo output only, 3 values kept for statistics / LayerNorm only, 0 anything else: tests at run time)
+    const int mode32 = p.act != ACT_NONE ? 0 : (p.out_f32 == 2 ? ((do_stats || LNF) ? 0 : 2) : ((do_stats || LNF) ? 3 : 1));
     constexpr int NCR = (WTN + 63) / 64;
     float cs[NCR], cq[NCR];
 #pragma unroll
@@ -963,10 +964,11 @@ __device__ __forceinline__ void gemm2_body(const GemmArgs& p) {
       }
       __builtin_amdgcn_wave_barrier();
       if (ps == 0) PP_STAMP(5);
-      // (PLAIN: no activation, no hi|lo output, nothing kept for statistics / LayerNorm -- tested once per pass instead of
-      //  four launch-uniform tests per chunk, each of which ended a basic block)
+      // (the launch-uniform tests -- activation, hi|lo output, values kept for statistics / LayerNorm -- are made once per
+      //  pass for the three common combinations instead of four times per chunk, where each ended a basic block)
       auto finish = [&](auto PLAIN, int idx, f32x4_t r, bool have_r) {   // row-segment chunk idx of this pass: residual, activation, store
-        constexpr bool plain = decltype(PLAIN)::value;
+        constexpr int mode = decltype(PLAIN)::value;          // 0 run-time tests, 1 plain, 2 hi|lo output only, 3 values kept only
+        constexpr bool plain = mode != 0;
         const int row = idx / CPR, ch = idx - row * CPR;
         const int m = mw + ps * IP * 16 + row, n = nw + ch * 4;
         f32x4_t v = *reinterpret_cast<const f32x4_t*>(slice + row * RS + ch * 16);
@@ -980,7 +982,7 @@ __device__ __forceinline__ void gemm2_body(const GemmArgs& p) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = silu_f(v[r]);
           }
-          if (!plain && p.out_f32 == 2) {   // hi|lo: [bf16(v) | bf16(v - bf16(v))] at columns n and N + n of a bf16 [M][2N] matrix
+          if (mode == 2 || (mode == 0 && p.out_f32 == 2)) {   // hi|lo: [bf16(v) | bf16(v - bf16(v))] at columns n and N + n of a bf16 [M][2N] matrix
             bf16_t* Ch = (bf16_t*)p.C + (size_t)batch * p.sC + out_row(m) * p.ldc + n;
             float hi[4], lo[4];
 #pragma unroll
@@ -990,19 +992,27 @@ __device__ __forceinline__ void gemm2_body(const GemmArgs& p) {
           } else {
             *reinterpret_cast<f32x4_t*>(C + out_row(m) * p.ldc + n) = v;
           }
-          if (!plain && (do_stats || LNF)) *reinterpret_cast<f32x4_t*>(slice + row * RS + ch * 16) = v;
+          if (mode == 3 || (mode == 0 && (do_stats || LNF))) *reinterpret_cast<f32x4_t*>(slice + row * RS + ch * 16) = v;
         }
       };
       if constexpr (RPRE) {
-        if (plain32) {
+        auto all = [&](auto MODE) {
 #pragma unroll
-          for (int it = 0; it < E_IT; ++it) finish(std::true_type{}, lane + it * 64, rpre[ps * E_IT + it], true);
+          for (int it = 0; it < E_IT; ++it) finish(MODE, lane + it * 64, rpre[ps * E_IT + it], true);
+        };
+        if constexpr (LNF) {   // (one copy: a second one of this pass spilled 11 registers)
+          all(std::integral_constant<int, 0>{});
+        } else if constexpr (F32 || EMU) {   // (f32 operands: two copies, the other two cost these kernels their second wave per SIMD)
+          if (mode32 == 1) all(std::integral_constant<int, 1>{});
+          else all(std::integral_constant<int, 0>{});
         } else {
-#pragma unroll
-          for (int it = 0; it < E_IT; ++it) finish(std::false_type{}, lane + it * 64, rpre[ps * E_IT + it], true);
+          if (mode32 == 1) all(std::integral_constant<int, 1>{});
+          else if (mode32 == 2) all(std::integral_constant<int, 2>{});
+          else if (mode32 == 3) all(std::integral_constant<int, 3>{});
+          else all(std::integral_constant<int, 0>{});
         }
       } else {
-        for (int idx = lane; idx < IP * 16 * CPR; idx += 64) finish(std::false_type{}, idx, (f32x4_t){0.f, 0.f, 0.f, 0.f}, false);
+        for (int idx = lane; idx < IP * 16 * CPR; idx += 64) finish(std::integral_constant<int, 0>{}, idx, (f32x4_t){0.f, 0.f, 0.f, 0.f}, false);
       }
       __builtin_amdgcn_wave_barrier();
       if (ps == 0) PP_STAMP(6);
