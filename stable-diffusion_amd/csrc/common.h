@@ -125,20 +125,25 @@ __device__ __forceinline__ float gelu_erf_f(float x) {
 // = x Q(x^2) on |x| <= 4.4 (clamped: 1 - erf(4.4 / sqrt 2) = 1.1e-5), Q of degree 8 fitted to a maximum error of 3.4e-5 in
 // erf = 7.4e-5 in the GELU at worst (x ~ 4), 1/50 of a bf16 rounding step there.  No v_rcp / v_exp (7.7 cycles each) and the
 // Horner chain packs two values per v_pk_fma_f32: the epilogue's math is what a GeGLU tile waits for after its K loop.
-__device__ __forceinline__ float gelu_erf_bf16out_f(float x) {
-  const float xc = __builtin_fminf(__builtin_fmaxf(x, -4.4f), 4.4f);
-  const float u = xc * xc;
-  float q = __builtin_fmaf(8.874779384e-11f, u, -8.991754896e-09f);
-  q = __builtin_fmaf(q, u, 4.008112171e-07f);
-  q = __builtin_fmaf(q, u, -1.045191675e-05f);
-  q = __builtin_fmaf(q, u, 1.796257420e-04f);
-  q = __builtin_fmaf(q, u, -2.180628711e-03f);
-  q = __builtin_fmaf(q, u, 1.953514107e-02f);
-  q = __builtin_fmaf(q, u, -1.325753778e-01f);
-  q = __builtin_fmaf(q, u, 7.977659106e-01f);
-  const float y = __builtin_fminf(__builtin_fmaxf(xc * q, -1.0f), 1.0f);
-  const float hx = 0.5f * x;
-  return __builtin_fmaf(hx, y, hx);
+// Two values at a time, so that every step is a packed instruction (v_pk_mul_f32 / v_pk_fma_f32).
+typedef __attribute__((ext_vector_type(2))) float gelu_f32x2_t;
+__device__ __forceinline__ gelu_f32x2_t gelu_erf_bf16out_f2(gelu_f32x2_t x) {
+  typedef gelu_f32x2_t v2;
+  const v2 xc = {__builtin_fminf(__builtin_fmaxf(x[0], -4.4f), 4.4f), __builtin_fminf(__builtin_fmaxf(x[1], -4.4f), 4.4f)};
+  const v2 u = xc * xc;
+  auto k = [](float c) { return (v2){c, c}; };
+  v2 q = __builtin_elementwise_fma(k(8.874779384e-11f), u, k(-8.991754896e-09f));
+  q = __builtin_elementwise_fma(q, u, k(4.008112171e-07f));
+  q = __builtin_elementwise_fma(q, u, k(-1.045191675e-05f));
+  q = __builtin_elementwise_fma(q, u, k(1.796257420e-04f));
+  q = __builtin_elementwise_fma(q, u, k(-2.180628711e-03f));
+  q = __builtin_elementwise_fma(q, u, k(1.953514107e-02f));
+  q = __builtin_elementwise_fma(q, u, k(-1.325753778e-01f));
+  q = __builtin_elementwise_fma(q, u, k(7.977659106e-01f));
+  const v2 yq = xc * q;
+  const v2 y = {__builtin_fminf(__builtin_fmaxf(yq[0], -1.0f), 1.0f), __builtin_fminf(__builtin_fmaxf(yq[1], -1.0f), 1.0f)};
+  const v2 hx = x * k(0.5f);
+  return __builtin_elementwise_fma(hx, y, hx);
 }
 __device__ __forceinline__ float quick_gelu_f(float x) { return x / (1.0f + expf(-1.702f * x)); }
 

@@ -912,8 +912,8 @@ __device__ __forceinline__ void gemm2_body(const GemmArgs& p) {
 #pragma unroll
               for (int r = 0; r < 4; ++r) v[r] *= gelu_erf_f(g[r]);
             } else {              // the product is stored as bf16: polynomial erf, no transcendentals (common.h)
-#pragma unroll
-              for (int r = 0; r < 4; ++r) v[r] *= gelu_erf_bf16out_f(g[r]);
+              const gelu_f32x2_t g01 = gelu_erf_bf16out_f2((gelu_f32x2_t){g[0], g[1]}), g23 = gelu_erf_bf16out_f2((gelu_f32x2_t){g[2], g[3]});
+              v[0] *= g01[0]; v[1] *= g01[1]; v[2] *= g23[0]; v[3] *= g23[1];
             }
             const u32x2_t o = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
             *reinterpret_cast<u32x2_t*>(slice + (ii * 16 + r16) * RS + ((j >> 1) * 16 + q4 * 4) * 2) = o;

@@ -352,7 +352,7 @@ def test_gemm_fused_geglu(M, C):
 
 def test_gemm_fused_geglu_polynomial_erf_against_the_exact_form():
     """The fused GeGLU epilogue rounds value * gelu(gate) to bf16 at once and uses a polynomial erf (common.h
-    gelu_erf_bf16out_f: degree 17, |x| <= 4.4 clamped, no v_rcp / v_exp); library debug word 29 keeps the 1.5e-7 form.
+    gelu_erf_bf16out_f2: degree 17, |x| <= 4.4 clamped, no v_rcp / v_exp); library debug word 29 keeps the 1.5e-7 form.
     Gates swept over [-9, 9] through an identity-like weight so that every regime (tails, clamp, zero crossing) is hit:
     the two forms agree to a small fraction of a bf16 rounding step, and both sit within one rounding of float64."""
     from sd_amd import _lib
