@@ -896,29 +896,36 @@ __device__ __forceinline__ void gemm2_body(const GemmArgs& p) {
       char* const slice = smem + wave * (IP * 16 * RS);
       bf16_t* __restrict__ C = (bf16_t*)p.C + (size_t)batch * p.sC;
       const int nwo = (n0 >> 1) + wn * WTO;                // first output column of this wave
+      // FAST = the usual launch (a bias, every column pair inside N, the polynomial GELU): no test inside the 16 sub-tile
+      // iterations -- with the three of the general form each iteration was basic blocks of its own.
+      const bool geglu_fast = has_bias && n0 + BN <= p.N && p.debug != 29;
 #pragma unroll
       for (int ps = 0; ps < TM / IP; ++ps) {
+        auto stage = [&](auto FAST) {
+          constexpr bool fast = decltype(FAST)::value;
 #pragma unroll
-        for (int ii = 0; ii < IP; ++ii) {
+          for (int ii = 0; ii < IP; ++ii) {
 #pragma unroll
-          for (int j = 0; j < TN; j += 2) {
-            f32x4_t v = acc[j][ps * IP + ii], g = acc[j + 1][ps * IP + ii];
-            const int n = nw + j * 16 + q4 * 4;
-            if (has_bias && n + 16 < p.N) {
-              v += bv[j];
-              g += bv[j + 1];
+            for (int j = 0; j < TN; j += 2) {
+              f32x4_t v = acc[j][ps * IP + ii], g = acc[j + 1][ps * IP + ii];
+              const int n = nw + j * 16 + q4 * 4;
+              if (fast || (has_bias && n + 16 < p.N)) {
+                v += bv[j];
+                g += bv[j + 1];
+              }
+              if (!fast && p.debug == 29) {   // (library debug word 29: the f32-accurate erf form, for A/B runs and the accuracy test)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] *= gelu_erf_f(g[r]);
+              } else {              // the product is stored as bf16: polynomial erf, no transcendentals (common.h)
+                const gelu_f32x2_t g01 = gelu_erf_bf16out_f2((gelu_f32x2_t){g[0], g[1]}), g23 = gelu_erf_bf16out_f2((gelu_f32x2_t){g[2], g[3]});
+                v[0] *= g01[0]; v[1] *= g01[1]; v[2] *= g23[0]; v[3] *= g23[1];
+              }
+              const u32x2_t o = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+              *reinterpret_cast<u32x2_t*>(slice + (ii * 16 + r16) * RS + ((j >> 1) * 16 + q4 * 4) * 2) = o;
             }
-            if (p.debug == 29) {   // (library debug word 29: the f32-accurate erf form, for A/B runs and the accuracy test)
-#pragma unroll
-              for (int r = 0; r < 4; ++r) v[r] *= gelu_erf_f(g[r]);
-            } else {              // the product is stored as bf16: polynomial erf, no transcendentals (common.h)
-              const gelu_f32x2_t g01 = gelu_erf_bf16out_f2((gelu_f32x2_t){g[0], g[1]}), g23 = gelu_erf_bf16out_f2((gelu_f32x2_t){g[2], g[3]});
-              v[0] *= g01[0]; v[1] *= g01[1]; v[2] *= g23[0]; v[3] *= g23[1];
-            }
-            const u32x2_t o = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
-            *reinterpret_cast<u32x2_t*>(slice + (ii * 16 + r16) * RS + ((j >> 1) * 16 + q4 * 4) * 2) = o;
           }
-        }
+        };
+        if (geglu_fast) stage(std::true_type{}); else stage(std::false_type{});
         __builtin_amdgcn_wave_barrier();
         if (ps == 0) PP_STAMP(5);
         for (int idx = lane; idx < IP * 16 * CPR; idx += 64) {
