@@ -1019,7 +1019,17 @@ __device__ __forceinline__ void gemm2_body(const GemmArgs& p) {
           else all(std::integral_constant<int, 0>{});
         }
       } else {
-        for (int idx = lane; idx < IP * 16 * CPR; idx += 64) finish(std::integral_constant<int, 0>{}, idx, (f32x4_t){0.f, 0.f, 0.f, 0.f}, false);
+        auto all = [&](auto MODE) {
+          for (int idx = lane; idx < IP * 16 * CPR; idx += 64) finish(MODE, idx, (f32x4_t){0.f, 0.f, 0.f, 0.f}, false);
+        };
+        if constexpr (F32 || EMU) {
+          all(std::integral_constant<int, 0>{});
+        } else {
+          if (mode32 == 1) all(std::integral_constant<int, 1>{});
+          else if (mode32 == 2) all(std::integral_constant<int, 2>{});
+          else if (mode32 == 3) all(std::integral_constant<int, 3>{});
+          else all(std::integral_constant<int, 0>{});
+        }
       }
       __builtin_amdgcn_wave_barrier();
       if (ps == 0) PP_STAMP(6);
